@@ -1,0 +1,93 @@
+/* C-ABI of libssie_hip.so — the MI355X (gfx950) hot path of SS-HSLIE.
+ *
+ * The reference (medemirhan/Self-supervised-Image-Enhancement-Network-Training-With-Low-Light-Images-Only)
+ * has no FFI of its own: its hot path is Python calling torch operators.  Each entry point below
+ * therefore names the reference call site(s) it replaces (paths relative to /root/reference).
+ * A maintainer binds them with ctypes; the package's own binding is
+ * `<pkg>/hostlib.py`.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 data unless stated otherwise; tensors are NHWC
+ *     ("band-innermost"); `cstride` = floats per pixel of the buffer, `coff` = first channel used;
+ *     cstride, coff and channel counts of multi-source inputs are multiples of 4 (16-byte vectors)
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue work
+ *   - functions never allocate device memory and never synchronise; scratch comes from the caller
+ *     (`ws`, sized by the matching *_workspace_bytes query)
+ *   - return value: 0 on success, >0 = argument/shape error (nothing was launched), see SSIE_E_*
+ *   - thread-compatible: one plan / one workspace must not be used from two threads at once
+ */
+#ifndef SSIE_HIP_H
+#define SSIE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSIE_E_OK 0
+#define SSIE_E_ARG 1        /* null pointer / bad enum */
+#define SSIE_E_SHAPE 2      /* unsupported shape or alignment */
+#define SSIE_E_WORKSPACE 3  /* workspace too small */
+#define SSIE_E_LAUNCH 4     /* HIP launch error */
+
+#define SSIE_ACT_NONE 0
+#define SSIE_ACT_RELU 1
+#define SSIE_ACT_SIGMOID 2
+
+/* one channel-slice of a virtual input: concat-by-pointer + nearest up-sampling on read
+ * (replaces torch.cat model.py:59,63,146,172 and F.interpolate model.py:156-169) */
+typedef struct {
+    const float* ptr;
+    int C, cstride, coff;
+    int Hs, Ws;               /* physical size; the op's (Hv, Wv) is the virtual (up-sampled) size */
+} ssie_src_t;
+
+const char* ssie_version(void);
+int ssie_device_ok(void);     /* 1 when the current HIP device is gfx950 */
+
+/* ---- granular operators (used by the parity tests; the plan below uses the same kernels) ---- */
+size_t ssie_op_workspace_bytes(int cin, int cout, int k);
+
+/* nn.Conv2d(+bias)(+ReLU|sigmoid)(+skip add): model.py:17-23, :47, :140-141; nn.Linear as k=1: model.py:93-97
+ * weight OIHW with cin_w input channels (<= sum of source C; extra source channels are zero padding);
+ * padding (k-1)/2; stride 1 or 2 (k=3).  out2 (optional) receives act(v) before the skip add. */
+int ssie_conv2d_fwd(const ssie_src_t* srcs, int nsrc, int N, int Hv, int Wv,
+                    const float* weight, int cin_w, const float* bias, int cout, int k, int stride, int act,
+                    const float* addsrc, float* out2, float* out, int out_cstride, int out_coff,
+                    void* ws, size_t ws_bytes, void* stream);
+
+/* nn.ConvTranspose2d(k=3, stride=2, padding=1, output_padding=1)(+ReLU): model.py:39-43; weight (in,out,k,k) */
+int ssie_conv_transpose2d_fwd(const ssie_src_t* src, int N, const float* weight, const float* bias, int cout,
+                              int act, float* out, int out_cstride, int out_coff,
+                              void* ws, size_t ws_bytes, void* stream);
+
+/* autograd backward of the above (model.py:315): data gradient w.r.t. input channels
+ * [ci_off, ci_off+cs) of a layer with cin_total inputs.  g = gradient w.r.t. the conv output
+ * (N,Ho,Wo,cout).  gx has the input's size (Hin,Win); optional mask multiplies by act'(mask_y)
+ * (mask_mode 1 = ReLU: y>0, 2 = sigmoid: y(1-y)); accumulate adds into gx. */
+int ssie_conv2d_dgrad(const float* g, int g_cstride, int g_coff, int N, int Ho, int Wo, int cout,
+                      const float* weight, int cin_total, int ci_off, int cs, int k, int stride,
+                      float* gx, int Hin, int Win, int gx_cstride, int gx_coff,
+                      const float* mask_y, int mask_mode, int accumulate,
+                      void* ws, size_t ws_bytes, void* stream);
+int ssie_conv_transpose2d_dgrad(const float* g, int g_cstride, int g_coff, int N, int Hin, int Win, int cout,
+                                const float* weight, int cin,
+                                float* gx, int gx_cstride, int gx_coff,
+                                const float* mask_y, int mask_mode, int accumulate,
+                                void* ws, size_t ws_bytes, void* stream);
+
+/* weight / bias gradient; dw in the parameter's own layout (OIHW, or (in,out,k,k) for the transposed
+ * conv); db may be NULL */
+int ssie_conv2d_wgrad(const ssie_src_t* src, int N, int Hv, int Wv,
+                      const float* g, int g_cstride, int g_coff, int cout, int k, int stride,
+                      int cin_total, int ci_off, float* dw, float* db, int accumulate,
+                      void* ws, size_t ws_bytes, void* stream);
+int ssie_conv_transpose2d_wgrad(const ssie_src_t* x, int N, const float* g, int g_cstride, int g_coff, int cout,
+                                float* dw, float* db, int accumulate,
+                                void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

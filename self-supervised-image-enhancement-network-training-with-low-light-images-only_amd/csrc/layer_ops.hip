@@ -1,0 +1,339 @@
+// Host-side geometry builders: turn "a layer of the reference network" into launches of the
+// implicit-GEMM kernels, and the granular C-ABI operators built on them.
+#include "layer_ops.h"
+#include "../../include/ssie_hip.h"
+#include <string.h>
+
+// ---------------------------------------------------------------------------------------------
+// tap lists
+// ---------------------------------------------------------------------------------------------
+TapList ssie_taps_conv(int k)
+{
+    TapList t; t.n = 0; const int pad = (k - 1) / 2;
+    for (int kh = 0; kh < k; ++kh) for (int kw = 0; kw < k; ++kw) {
+        t.dy[t.n] = (int8_t)(kh - pad); t.dx[t.n] = (int8_t)(kw - pad); t.sel[t.n] = (int8_t)(kh * k + kw); ++t.n;
+    }
+    return t;
+}
+// data gradient of a stride-1 conv: gX[y] = sum_kh G[y + pad - kh] W[kh]
+TapList ssie_taps_dgrad_s1(int k)
+{
+    TapList t; t.n = 0; const int pad = (k - 1) / 2;
+    for (int kh = 0; kh < k; ++kh) for (int kw = 0; kw < k; ++kw) {
+        t.dy[t.n] = (int8_t)(pad - kh); t.dx[t.n] = (int8_t)(pad - kw); t.sel[t.n] = (int8_t)(kh * k + kw); ++t.n;
+    }
+    return t;
+}
+// transposed conv (stride 2): output y = 2a - pad + kh.  For output parity py only taps with
+// kh = py + pad (mod 2) contribute, reading input row a' + (py + pad - kh)/2.
+TapList ssie_taps_transposed(int k, int pad, int py, int px)
+{
+    TapList t; t.n = 0;
+    for (int kh = 0; kh < k; ++kh) {
+        int ny = py + pad - kh; if (ny & 1) continue;
+        for (int kw = 0; kw < k; ++kw) {
+            int nx = px + pad - kw; if (nx & 1) continue;
+            t.dy[t.n] = (int8_t)(ny / 2); t.dx[t.n] = (int8_t)(nx / 2); t.sel[t.n] = (int8_t)(kh * k + kw); ++t.n;
+        }
+    }
+    return t;
+}
+
+static void tap_extent(const TapList& t, int& mn_y, int& mx_y, int& mn_x, int& mx_x)
+{
+    mn_y = mn_x = 127; mx_y = mx_x = -127;
+    for (int i = 0; i < t.n; ++i) {
+        if (t.dy[i] < mn_y) mn_y = t.dy[i]; if (t.dy[i] > mx_y) mx_y = t.dy[i];
+        if (t.dx[i] < mn_x) mn_x = t.dx[i]; if (t.dx[i] > mx_x) mx_x = t.dx[i];
+    }
+}
+
+SrcDesc ssie_make_src(const float* ptr, int C, int cstride, int coff, int Hs, int Ws, int Hv, int Wv)
+{
+    SrcDesc s; s.ptr = ptr; s.C = C; s.cstride = cstride; s.coff = coff; s.Hs = Hs; s.Ws = Ws;
+    // F.interpolate(mode='nearest', size=...) uses scale = (float)in / out (model.py:156-169)
+    s.sy = (Hs == Hv) ? 1.0f : (float)Hs / (float)Hv;
+    s.sx = (Ws == Wv) ? 1.0f : (float)Ws / (float)Wv;
+    return s;
+}
+
+size_t ssie_packed_floats(int K, int N, int T)
+{
+    const int npad = N > 32 ? ssie_round_up(N, 64) : 32;
+    return (size_t)ssie_ceil_div(K, SSIE_CK) * T * 16 * npad;
+}
+
+PackDesc ssie_make_pack(const float* w, float* dst, int K, int N, const TapList& t, int s_k, int s_n, int s_t)
+{
+    PackDesc d; memset(&d, 0, sizeof(d));
+    d.w = w; d.dst = dst; d.K = K; d.N = N; d.Npad = N > 32 ? ssie_round_up(N, 64) : 32; d.T = t.n;
+    d.nchunks = ssie_ceil_div(K, SSIE_CK); d.s_k = s_k; d.s_n = s_n; d.s_t = s_t;
+    for (int i = 0; i < t.n; ++i) d.tapsel[i] = t.sel[i];
+    return d;
+}
+
+int ssie_make_conv(ConvParams& p, const SrcDesc* srcs, int nsrc, int N, int Hv, int Wv, const TapList& t, int si,
+                   int Ho, int Wo, const float* wpacked, int Cout,
+                   float* out, int Hout, int Wout, int out_cstride, int out_coff, int so, int py, int px,
+                   const Epilogue& e)
+{
+    memset(&p, 0, sizeof(p));
+    if (nsrc < 1 || nsrc > SSIE_MAX_SRC || t.n < 1 || t.n > SSIE_MAX_TAPS) return SSIE_E_ARG;
+    int cin = 0;
+    for (int s = 0; s < nsrc; ++s) {
+        p.src[s] = srcs[s];
+        if (srcs[s].C % 4 || srcs[s].cstride % 4 || srcs[s].coff % 4) return SSIE_E_SHAPE;
+        if (nsrc > 1 && srcs[s].C % SSIE_CK) return SSIE_E_SHAPE;
+        if (((uintptr_t)srcs[s].ptr) % 16) return SSIE_E_SHAPE;
+        cin += srcs[s].C;
+    }
+    p.nsrc = nsrc; p.N = N; p.Hv = Hv; p.Wv = Wv; p.Cin = cin; p.nchunks = ssie_ceil_div(cin, SSIE_CK);
+    p.Ho = Ho; p.Wo = Wo; p.si = si; p.ntaps = t.n;
+    int mny, mxy, mnx, mxx; tap_extent(t, mny, mxy, mnx, mxx);
+    p.min_dy = mny; p.min_dx = mnx;
+    p.hp_h = (SSIE_TH - 1) * si + (mxy - mny) + 1;
+    p.hp_w = (SSIE_TW - 1) * si + (mxx - mnx) + 1;
+    for (int i = 0; i < t.n; ++i) { p.tap_dy[i] = t.dy[i]; p.tap_dx[i] = t.dx[i]; }
+    p.wpacked = wpacked; p.Cout = Cout; p.Cout_pad = Cout > 32 ? ssie_round_up(Cout, 64) : 32;
+    p.out = out; p.out_cstride = out_cstride; p.out_coff = out_coff; p.Hout = Hout; p.Wout = Wout;
+    p.so = so; p.py = py; p.px = px;
+    p.bias = e.bias; p.act = e.act; p.addsrc = e.addsrc; p.out2 = e.out2; p.mask_y = e.mask_y;
+    p.mask_mode = e.mask_y ? e.mask_mode : MASK_NONE; p.accumulate = e.accumulate;
+    p.tiles_y = ssie_ceil_div(Ho, SSIE_TH); p.tiles_x = ssie_ceil_div(Wo, SSIE_TW);
+    p.co_blocks = p.Cout_pad > 32 ? p.Cout_pad / 64 : 1;
+    return 0;
+}
+
+int ssie_make_wgrad(WgradParams& p, const SrcDesc& src, int N, int Hv, int Wv, int ci0_weight,
+                    const float* g, int g_cstride, int g_coff, int Cout, int Ho, int Wo, int si,
+                    const TapList& t, float* slabs, int target_wgs)
+{
+    memset(&p, 0, sizeof(p));
+    if (src.C % 4 || src.cstride % 4 || src.coff % 4 || g_cstride % 4 || g_coff % 4) return SSIE_E_SHAPE;
+    p.src = src; p.N = N; p.Hv = Hv; p.Wv = Wv; p.ci0_total = ci0_weight; p.Cin = src.C;
+    p.g = g; p.g_cstride = g_cstride; p.g_coff = g_coff; p.Cout = Cout; p.Ho = Ho; p.Wo = Wo; p.si = si;
+    p.ntaps = t.n;
+    int mny, mxy, mnx, mxx; tap_extent(t, mny, mxy, mnx, mxx);
+    p.min_dy = mny; p.min_dx = mnx;
+    p.th = si == 1 ? 8 : 4;
+    p.hp_h = (p.th - 1) * si + (mxy - mny) + 1;
+    p.hp_w = (SSIE_TW - 1) * si + (mxx - mnx) + 1;
+    for (int i = 0; i < t.n; ++i) { p.tap_dy[i] = t.dy[i]; p.tap_dx[i] = t.dx[i]; }
+    const int cib = src.C > 32 ? 64 : 32, cob = Cout > 32 ? 64 : 32;
+    p.ci_blocks = ssie_ceil_div(src.C, cib); p.co_blocks = ssie_ceil_div(Cout, cob);
+    p.ci_pad = p.ci_blocks * cib; p.co_pad = p.co_blocks * cob;
+    p.tap_groups = ssie_ceil_div(t.n, SSIE_TG);
+    p.tiles_y = ssie_ceil_div(Ho, p.th); p.tiles_x = ssie_ceil_div(Wo, SSIE_TW);
+    p.tiles_total = N * p.tiles_y * p.tiles_x;
+    int per = p.ci_blocks * p.co_blocks * p.tap_groups;
+    int ns = target_wgs / per; if (ns < 1) ns = 1; if (ns > p.tiles_total) ns = p.tiles_total;
+    p.nslices = ns;
+    p.slabs = slabs;
+    return 0;
+}
+
+size_t ssie_wgrad_slab_floats(const WgradParams& p) { return (size_t)p.nslices * p.ntaps * p.ci_pad * p.co_pad; }
+
+// ---------------------------------------------------------------------------------------------
+// granular C-ABI
+// ---------------------------------------------------------------------------------------------
+static const int kTargetWgs = 512;
+
+extern "C" const char* ssie_version(void) { return "ssie-hip 0.1 (gfx950, fp32 MFMA 32x32x2)"; }
+
+extern "C" int ssie_device_ok(void)
+{
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    return strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+}
+
+extern "C" size_t ssie_op_workspace_bytes(int cin, int cout, int k)
+{
+    const int T = k * k;
+    size_t packed = 4 * ssie_packed_floats(cin > cout ? cin : cout, cin > cout ? cin : cout, T);
+    size_t slabs = (size_t)kTargetWgs * (T < SSIE_TG ? T : SSIE_TG) * 64 * 64 + (size_t)T * ssie_round_up(cin, 64) * ssie_round_up(cout, 64);
+    size_t partial = (size_t)256 * ssie_round_up(cout > cin ? cout : cin, 4);
+    return (packed + slabs * 2 + partial) * sizeof(float) + 4096;
+}
+
+static inline float* ws_take(char*& cur, char* end, size_t floats)
+{
+    size_t bytes = (floats * 4 + 255) & ~(size_t)255;
+    if (cur + bytes > end) return nullptr;
+    float* r = (float*)cur; cur += bytes; return r;
+}
+
+extern "C" int ssie_conv2d_fwd(const ssie_src_t* srcs, int nsrc, int N, int Hv, int Wv,
+                               const float* weight, int cin_w, const float* bias, int cout, int k, int stride, int act,
+                               const float* addsrc, float* out2, float* out, int out_cstride, int out_coff,
+                               void* ws, size_t ws_bytes, void* stream)
+{
+    if (!srcs || !weight || !out || !ws) return SSIE_E_ARG;
+    if (!(stride == 1 || (stride == 2 && k == 3)) || !(k & 1) || k > 9) return SSIE_E_SHAPE;
+    SrcDesc sd[SSIE_MAX_SRC]; int cin = 0;
+    if (nsrc < 1 || nsrc > SSIE_MAX_SRC) return SSIE_E_ARG;
+    for (int s = 0; s < nsrc; ++s) { sd[s] = ssie_make_src(srcs[s].ptr, srcs[s].C, srcs[s].cstride, srcs[s].coff, srcs[s].Hs, srcs[s].Ws, Hv, Wv); cin += srcs[s].C; }
+    const int pad = (k - 1) / 2, T = k * k;
+    const int Ho = (Hv + 2 * pad - k) / stride + 1, Wo = (Wv + 2 * pad - k) / stride + 1;
+    char* cur = (char*)ws; char* end = cur + ws_bytes;
+    if (cin_w > cin || ssie_ceil_div(cin_w, SSIE_CK) != ssie_ceil_div(cin, SSIE_CK)) return SSIE_E_SHAPE;
+    float* wp = ws_take(cur, end, ssie_packed_floats(cin_w, cout, T));
+    if (!wp) return SSIE_E_WORKSPACE;
+    TapList t = ssie_taps_conv(k);
+    PackDesc pd = ssie_make_pack(weight, wp, cin_w, cout, t, /*s_k*/ T, /*s_n*/ cin_w * T, 1);
+    hipStream_t st = (hipStream_t)stream;
+    if (ssie_launch_pack(pd, st)) return SSIE_E_LAUNCH;
+    Epilogue e; memset(&e, 0, sizeof(e)); e.bias = bias; e.act = act; e.addsrc = addsrc; e.out2 = out2;
+    ConvParams p;
+    int rc = ssie_make_conv(p, sd, nsrc, N, Hv, Wv, t, stride, Ho, Wo, wp, cout, out, Ho, Wo, out_cstride, out_coff, 1, 0, 0, e);
+    if (rc) return rc;
+    return ssie_launch_fprop(p, st) ? SSIE_E_LAUNCH : 0;
+}
+
+// shared by ConvTranspose2d fprop and the data gradient of a stride-2 conv:
+// out[2a+py][2b+px][n] = sum_taps in[a+dy][b+dx][k] * W(k, n, tap)
+static int transposed_like(const SrcDesc& in, int N, int Hin, int Win, int Kc, int Nc, const float* weight,
+                           int s_k, int s_n, float* out, int Hout, int Wout, int out_cstride, int out_coff,
+                           const Epilogue& e, char*& cur, char* end, hipStream_t st)
+{
+    for (int py = 0; py < 2; ++py) for (int px = 0; px < 2; ++px) {
+        TapList t = ssie_taps_transposed(3, 1, py, px);
+        float* wp = ws_take(cur, end, ssie_packed_floats(Kc, Nc, t.n));
+        if (!wp) return SSIE_E_WORKSPACE;
+        PackDesc pd = ssie_make_pack(weight, wp, Kc, Nc, t, s_k, s_n, 1);
+        if (ssie_launch_pack(pd, st)) return SSIE_E_LAUNCH;
+        ConvParams p;
+        const int Ho = ssie_ceil_div(Hout - py, 2), Wo = ssie_ceil_div(Wout - px, 2);
+        int rc = ssie_make_conv(p, &in, 1, N, Hin, Win, t, 1, Ho, Wo, wp, Nc, out, Hout, Wout, out_cstride, out_coff, 2, py, px, e);
+        if (rc) return rc;
+        if (ssie_launch_fprop(p, st)) return SSIE_E_LAUNCH;
+    }
+    return 0;
+}
+
+extern "C" int ssie_conv_transpose2d_fwd(const ssie_src_t* src, int N, const float* weight, const float* bias, int cout,
+                                         int act, float* out, int out_cstride, int out_coff,
+                                         void* ws, size_t ws_bytes, void* stream)
+{
+    if (!src || !weight || !out || !ws) return SSIE_E_ARG;
+    SrcDesc in = ssie_make_src(src->ptr, src->C, src->cstride, src->coff, src->Hs, src->Ws, src->Hs, src->Ws);
+    char* cur = (char*)ws; char* end = cur + ws_bytes;
+    Epilogue e; memset(&e, 0, sizeof(e)); e.bias = bias; e.act = act;
+    // weight (in, out, 3, 3): k = ci -> stride cout*9, n = co -> stride 9
+    return transposed_like(in, N, src->Hs, src->Ws, src->C, cout, weight, cout * 9, 9, out, 2 * src->Hs, 2 * src->Ws,
+                           out_cstride, out_coff, e, cur, end, (hipStream_t)stream);
+}
+
+extern "C" int ssie_conv2d_dgrad(const float* g, int g_cstride, int g_coff, int N, int Ho, int Wo, int cout,
+                                 const float* weight, int cin_total, int ci_off, int cs, int k, int stride,
+                                 float* gx, int Hin, int Win, int gx_cstride, int gx_coff,
+                                 const float* mask_y, int mask_mode, int accumulate,
+                                 void* ws, size_t ws_bytes, void* stream)
+{
+    if (!g || !weight || !gx || !ws) return SSIE_E_ARG;
+    if (!(stride == 1 || (stride == 2 && k == 3))) return SSIE_E_SHAPE;
+    const int T = k * k;
+    hipStream_t st = (hipStream_t)stream;
+    char* cur = (char*)ws; char* end = cur + ws_bytes;
+    SrcDesc in = ssie_make_src(g, ssie_round_up(cout, 4), g_cstride, g_coff, Ho, Wo, Ho, Wo);
+    Epilogue e; memset(&e, 0, sizeof(e)); e.mask_y = mask_y; e.mask_mode = mask_mode; e.accumulate = accumulate;
+    const float* wbase = weight + (size_t)ci_off * T;
+    if (stride == 1) {
+        TapList t = ssie_taps_dgrad_s1(k);
+        float* wp = ws_take(cur, end, ssie_packed_floats(cout, cs, T));
+        if (!wp) return SSIE_E_WORKSPACE;
+        // OIHW: k = co -> stride cin_total*T, n = ci -> stride T
+        PackDesc pd = ssie_make_pack(wbase, wp, cout, cs, t, cin_total * T, T, 1);
+        if (ssie_launch_pack(pd, st)) return SSIE_E_LAUNCH;
+        ConvParams p;
+        int rc = ssie_make_conv(p, &in, 1, N, Ho, Wo, t, 1, Hin, Win, wp, cs, gx, Hin, Win, gx_cstride, gx_coff, 1, 0, 0, e);
+        if (rc) return rc;
+        return ssie_launch_fprop(p, st) ? SSIE_E_LAUNCH : 0;
+    }
+    return transposed_like(in, N, Ho, Wo, cout, cs, wbase, cin_total * T, T, gx, Hin, Win, gx_cstride, gx_coff, e, cur, end, st);
+}
+
+extern "C" int ssie_conv_transpose2d_dgrad(const float* g, int g_cstride, int g_coff, int N, int Hin, int Win, int cout,
+                                           const float* weight, int cin,
+                                           float* gx, int gx_cstride, int gx_coff,
+                                           const float* mask_y, int mask_mode, int accumulate,
+                                           void* ws, size_t ws_bytes, void* stream)
+{
+    if (!g || !weight || !gx || !ws) return SSIE_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    char* cur = (char*)ws; char* end = cur + ws_bytes;
+    // gX[a][ci] = sum_{kh,co} G[2a-1+kh][co] W[ci][co][kh]  == stride-2 conv of G with W read as OIHW (O=ci, I=co)
+    SrcDesc in = ssie_make_src(g, ssie_round_up(cout, 4), g_cstride, g_coff, 2 * Hin, 2 * Win, 2 * Hin, 2 * Win);
+    TapList t = ssie_taps_conv(3);
+    float* wp = ws_take(cur, end, ssie_packed_floats(cout, cin, 9));
+    if (!wp) return SSIE_E_WORKSPACE;
+    PackDesc pd = ssie_make_pack(weight, wp, cout, cin, t, /*k=co*/ 9, /*n=ci*/ cout * 9, 1);
+    if (ssie_launch_pack(pd, st)) return SSIE_E_LAUNCH;
+    Epilogue e; memset(&e, 0, sizeof(e)); e.mask_y = mask_y; e.mask_mode = mask_mode; e.accumulate = accumulate;
+    ConvParams p;
+    int rc = ssie_make_conv(p, &in, 1, N, 2 * Hin, 2 * Win, t, 2, Hin, Win, wp, cin, gx, Hin, Win, gx_cstride, gx_coff, 1, 0, 0, e);
+    if (rc) return rc;
+    return ssie_launch_fprop(p, st) ? SSIE_E_LAUNCH : 0;
+}
+
+int ssie_run_wgrad(const SrcDesc& x, int x_creal, int N, int Hv, int Wv, const float* g, int g_cstride, int g_coff, int gC,
+                   int Ho, int Wo, int si, const TapList& t, float* dw, long s_co, long s_ci, long s_t,
+                   int accumulate, float* slabs, size_t slab_cap_floats, hipStream_t st)
+{
+    WgradParams p;
+    int rc = ssie_make_wgrad(p, x, N, Hv, Wv, 0, g, g_cstride, g_coff, gC, Ho, Wo, si, t, slabs, kTargetWgs);
+    if (rc) return rc;
+    if (ssie_wgrad_slab_floats(p) > slab_cap_floats) return SSIE_E_WORKSPACE;
+    if (ssie_launch_wgrad(p, st)) return SSIE_E_LAUNCH;
+    if (ssie_launch_wgrad_reduce(slabs, p.nslices, p.ntaps, p.ci_pad, p.co_pad, x_creal, gC, dw, s_co, s_ci, s_t, accumulate, st)) return SSIE_E_LAUNCH;
+    return 0;
+}
+
+extern "C" int ssie_conv2d_wgrad(const ssie_src_t* src, int N, int Hv, int Wv,
+                                 const float* g, int g_cstride, int g_coff, int cout, int k, int stride,
+                                 int cin_total, int ci_off, float* dw, float* db, int accumulate,
+                                 void* ws, size_t ws_bytes, void* stream)
+{
+    if (!src || !g || !dw || !ws) return SSIE_E_ARG;
+    if (!(stride == 1 || (stride == 2 && k == 3))) return SSIE_E_SHAPE;
+    const int pad = (k - 1) / 2, T = k * k;
+    const int Ho = (Hv + 2 * pad - k) / stride + 1, Wo = (Wv + 2 * pad - k) / stride + 1;
+    hipStream_t st = (hipStream_t)stream;
+    char* cur = (char*)ws; char* end = cur + ws_bytes;
+    float* partial = ws_take(cur, end, (size_t)256 * cout);
+    if (!partial) return SSIE_E_WORKSPACE;
+    size_t cap = (size_t)(end - cur) / 4;
+    SrcDesc x = ssie_make_src(src->ptr, src->C, src->cstride, src->coff, src->Hs, src->Ws, Hv, Wv);
+    TapList t = ssie_taps_conv(k);
+    int creal = src->C < cin_total - ci_off ? src->C : cin_total - ci_off;
+    int rc = ssie_run_wgrad(x, creal, N, Hv, Wv, g, g_cstride, g_coff, cout, Ho, Wo, stride, t,
+                            dw + (size_t)ci_off * T, (long)cin_total * T, T, 1, accumulate, (float*)cur, cap, st);
+    if (rc) return rc;
+    if (db && ssie_launch_colsum(g, (long)N * Ho * Wo, g_cstride, g_coff, cout, partial, 256, db, accumulate, st)) return SSIE_E_LAUNCH;
+    return 0;
+}
+
+extern "C" int ssie_conv_transpose2d_wgrad(const ssie_src_t* x, int N, const float* g, int g_cstride, int g_coff, int cout,
+                                           float* dw, float* db, int accumulate,
+                                           void* ws, size_t ws_bytes, void* stream)
+{
+    if (!x || !g || !dw || !ws) return SSIE_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    char* cur = (char*)ws; char* end = cur + ws_bytes;
+    float* partial = ws_take(cur, end, (size_t)256 * cout);
+    if (!partial) return SSIE_E_WORKSPACE;
+    size_t cap = (size_t)(end - cur) / 4;
+    const int Hin = x->Hs, Win = x->Ws, cin = x->C;
+    // dW[ci][co][kh][kw] = sum_{a,b} x[a][b][ci] * G[2a-1+kh][2b-1+kw][co]: a stride-2 wgrad with the roles
+    // swapped: "input" = G (hi-res, cout channels), "output gradient" = x (lo-res, cin channels)
+    SrcDesc gs = ssie_make_src(g, ssie_round_up(cout, 4), g_cstride, g_coff, 2 * Hin, 2 * Win, 2 * Hin, 2 * Win);
+    TapList t = ssie_taps_conv(3);
+    // slab [t][ci' = co][co' = ci]  ->  dw[(ci*cout + co)*9 + t]
+    int rc = ssie_run_wgrad(gs, cout, N, 2 * Hin, 2 * Win, x->ptr, x->cstride, x->coff, cin, Hin, Win, 2, t,
+                            dw, /*s_co (co'=ci)*/ (long)cout * 9, /*s_ci (ci'=co)*/ 9, 1, accumulate, (float*)cur, cap, st);
+    if (rc) return rc;
+    if (db && ssie_launch_colsum(g, (long)N * 4 * Hin * Win, g_cstride, g_coff, cout, partial, 256, db, accumulate, st)) return SSIE_E_LAUNCH;
+    return 0;
+}

@@ -1,0 +1,100 @@
+// Shared host/device declarations for the SS-HSLIE MI355X (gfx950) hot path.
+//
+// Data layout (all device tensors): fp32, NHWC ("band-innermost"), the channel count of
+// every buffer padded to a multiple of 4 so that each pixel's band vector is 16-byte
+// aligned.  The reference hands the model channels_last tensors (model.py:301,312), so the
+// band axis is already the fastest-moving one.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SSIE_MAX_SRC 3
+#define SSIE_MAX_TAPS 81
+#define SSIE_TG 9            // taps staged per weight-group (one 3x3 kernel, or one row of the 9x9)
+#define SSIE_CK 16           // input channels per K-chunk
+#define SSIE_TH 8            // output tile rows
+#define SSIE_TW 16           // output tile cols
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// One source of a "virtual input" tensor: channel-concatenation by pointer, nearest
+// up-sampling on read (F.interpolate(mode='nearest'), model.py:156-169) and zero padding
+// are all resolved while staging the LDS halo tile, so no cat/interpolate copy ever exists.
+struct SrcDesc {
+    const float* ptr;
+    int C;         // channels taken from this source (multiple of 16 when nsrc > 1)
+    int cstride;   // floats per pixel in the buffer
+    int coff;      // first channel inside the pixel
+    int Hs, Ws;    // physical spatial size
+    float sy, sx;  // nearest scale: src = min((int)floorf(v * s), Hs - 1); 1.0f = identity
+};
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
+enum { MASK_NONE = 0, MASK_RELU = 1, MASK_SIGMOID = 2 };   // multiply by act'(y) given stored y
+
+struct ConvParams {
+    SrcDesc src[SSIE_MAX_SRC];
+    int nsrc;
+    int N, Hv, Wv;          // virtual input size
+    int Cin;                // total virtual channels
+    int nchunks;            // ceil(Cin / 16)
+    int Ho, Wo;             // output-position grid enumerated by the tiles
+    int si;                 // input stride of the position grid (1 or 2)
+    int ntaps;
+    int min_dy, min_dx;     // halo origin relative to (a*si, b*si)
+    int hp_h, hp_w;         // halo tile size in pixels
+    int8_t tap_dy[SSIE_MAX_TAPS];
+    int8_t tap_dx[SSIE_MAX_TAPS];
+    const float* wpacked;   // [chunk][tap][kq*2+h][Cout_pad][4]
+    int Cout, Cout_pad;
+    float* out;             // output tensor
+    int out_cstride, out_coff;
+    int Hout, Wout;         // physical output size
+    int so, py, px;         // output position = (a*so + py, b*so + px)
+    const float* bias;      // may be null
+    int act;
+    const float* addsrc;    // optional skip tensor (same geometry as out): out = act(v) + addsrc
+    float* out2;            // optional second store of act(v) (pre-skip value, needed for ReLU mask)
+    const float* mask_y;    // optional: v *= act'(mask_y) (same geometry as out)
+    int mask_mode;
+    int accumulate;         // out += v instead of out = v
+    int tiles_y, tiles_x, co_blocks;
+};
+
+struct WgradParams {
+    SrcDesc src;            // the layer input (single source per launch)
+    int N, Hv, Wv;
+    int ci0_total;          // first weight input-channel this source maps to (concat offset)
+    int Cin;                // channels of this source
+    const float* g;         // output gradient (pre-activation), NHWC
+    int g_cstride, g_coff, Cout;
+    int Ho, Wo, si;
+    int ntaps, min_dy, min_dx, hp_h, hp_w;
+    int8_t tap_dy[SSIE_MAX_TAPS];
+    int8_t tap_dx[SSIE_MAX_TAPS];
+    float* slabs;           // [slice][tap][ci_pad][co_pad]
+    int ci_pad, co_pad;
+    int nslices, tiles_total, tiles_y, tiles_x, th;
+    int ci_blocks, co_blocks, tap_groups;
+};
+
+struct PackDesc {
+    const float* w; float* dst;
+    int K, N, Npad, T, nchunks;
+    int s_k, s_n, s_t;
+    int8_t tapsel[SSIE_MAX_TAPS];
+};
+
+// host launchers (conv_kernels.hip); return 0 on success
+int ssie_launch_fprop(const ConvParams& p, hipStream_t st);
+int ssie_launch_wgrad(const WgradParams& p, hipStream_t st);
+int ssie_launch_wgrad_reduce(const float* slabs, int nslices, int ntaps, int ci_pad, int co_pad, int Cin, int Cout,
+                             float* dst, long s_co, long s_ci, long s_t, int accumulate, hipStream_t st);
+int ssie_launch_colsum(const float* g, long npix, int cstride, int coff, int C, float* partial, int nblk,
+                       float* dst, int accumulate, hipStream_t st);
+int ssie_launch_pack(const PackDesc& d, hipStream_t st);
+int ssie_launch_pack_batched(const PackDesc* descs_dev, int ndesc, hipStream_t st);
+
+static inline int ssie_ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int ssie_round_up(int a, int b) { return ssie_ceil_div(a, b) * b; }

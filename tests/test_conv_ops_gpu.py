@@ -1,0 +1,180 @@
+"""GPU parity of the MFMA implicit-GEMM conv operators (through the C-ABI) against a plain PyTorch
+CPU float64 reference of the same op.  Tolerance: |err| <= 2e-5 * max|ref| (fp32 fma chains of up to
+K = 2592 terms; SURVEY §8(c) measured fp32-vs-fp64 self-agreement of the reference at ~1e-7..1e-6).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def H():
+    import ssie
+    ssie.load()
+    from ssie_amd import hostlib
+    assert hostlib.lib().ssie_device_ok() == 1
+    return hostlib
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g, dtype=torch.float64) * 2 - 1) * scale
+
+
+def to_dev(H, t):
+    """NCHW float64 cpu -> NHWC fp32 cuda padded"""
+    return H.nhwc(t.float().cuda())
+
+
+def from_dev(buf, c):
+    return buf[..., :c].permute(0, 3, 1, 2).double().cpu()
+
+
+def close(got, ref, tol=TOL):
+    scale = max(ref.abs().max().item(), 1e-30)
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, f"max err {err:.3e} vs scale {scale:.3e} (rel {err/scale:.3e})"
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,h,w,act", [
+    (32, 64, 3, 1, 16, 32, 1),
+    (32, 64, 3, 1, 20, 24, 0),
+    (31, 64, 9, 1, 16, 16, 0),
+    (31, 32, 3, 1, 18, 22, 1),
+    (64, 128, 3, 2, 32, 32, 1),
+    (64, 64, 3, 2, 26, 50, 1),
+    (128, 128, 3, 1, 16, 16, 1),
+    (64, 32, 3, 1, 16, 16, 2),
+    (64, 1, 3, 1, 16, 32, 0),
+    (5, 32, 3, 1, 16, 16, 1),
+    (5, 64, 9, 1, 24, 16, 0),
+    (64, 192, 1, 1, 8, 32, 0),
+])
+def test_conv2d_fwd(H, cin, cout, k, stride, h, w, act):
+    n = 2
+    x = rnd(n, cin, h, w, seed=1)
+    wt = rnd(cout, cin, k, k, seed=2, scale=0.2)
+    b = rnd(cout, seed=3)
+    ref = F.conv2d(x, wt, b, stride=stride, padding=(k - 1) // 2)
+    ref = F.relu(ref) if act == 1 else (torch.sigmoid(ref) if act == 2 else ref)
+    xb = to_dev(H, x)
+    out = H.conv2d_fwd([(xb, (cin + 3) // 4 * 4, 0)], h, w, wt.float().cuda(), b.float().cuda(), k, stride, act)
+    torch.cuda.synchronize()
+    close(from_dev(out, cout), ref)
+
+
+def test_conv2d_fwd_concat_upsample_skip(H):
+    """conv7-like concat (64+32), deconvN-like nearest-upsample-on-read + skip add + out2, fusion-like 3 sources."""
+    n, h, w = 2, 16, 32
+    a = rnd(n, 64, h, w, seed=1); c = rnd(n, 32, h, w, seed=2)
+    wt = rnd(64, 96, 3, 3, seed=3, scale=0.1); b = rnd(64, seed=4)
+    ref = F.conv2d(torch.cat([a, c], 1), wt, b, padding=1)
+    out = H.conv2d_fwd([(to_dev(H, a), 64, 0), (to_dev(H, c), 32, 0)], h, w, wt.float().cuda(), b.float().cuda(), 3)
+    close(from_dev(out, 64), ref)
+
+    for (hs, ws_, hv, wv) in ((8, 16, 16, 32), (13, 7, 25, 13)):
+        lo = rnd(n, 64, hs, ws_, seed=5); skip = rnd(n, 64, hv, wv, seed=6)
+        up = F.interpolate(lo.float(), size=(hv, wv), mode="nearest").double()
+        pre = F.relu(F.conv2d(up, wt[:, :64], b, padding=1))
+        out, out2 = H.conv2d_fwd([(to_dev(H, lo), 64, 0)], hv, wv, wt[:, :64].contiguous().float().cuda(),
+                                 b.float().cuda(), 3, act=1, addsrc=to_dev(H, skip), want_out2=True)
+        close(from_dev(out2, 64), pre)
+        close(from_dev(out, 64), pre + skip)
+
+    d1 = rnd(n, 64, 4, 8, seed=7); d2 = rnd(n, 64, 8, 16, seed=8); d3 = rnd(n, 64, 16, 32, seed=9)
+    w1 = rnd(64, 192, 1, 1, seed=10, scale=0.1)
+    cat = torch.cat([F.interpolate(d1.float(), size=(16, 32), mode="nearest").double(),
+                     F.interpolate(d2.float(), size=(16, 32), mode="nearest").double(), d3], 1)
+    ref = F.conv2d(cat, w1, b)
+    out = H.conv2d_fwd([(to_dev(H, d1), 64, 0), (to_dev(H, d2), 64, 0), (to_dev(H, d3), 64, 0)], 16, 32,
+                       w1.float().cuda(), b.float().cuda(), 1)
+    close(from_dev(out, 64), ref)
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(128, 64, 16, 16), (64, 64, 9, 20), (16, 32, 8, 8)])
+def test_conv_transpose2d_fwd(H, cin, cout, h, w):
+    n = 2
+    x = rnd(n, cin, h, w, seed=1); wt = rnd(cin, cout, 3, 3, seed=2, scale=0.1); b = rnd(cout, seed=3)
+    ref = F.relu(F.conv_transpose2d(x, wt, b, stride=2, padding=1, output_padding=1))
+    out = H.conv_transpose2d_fwd(to_dev(H, x), wt.float().cuda(), b.float().cuda(), act=1)
+    close(from_dev(out, cout), ref)
+
+
+def _conv_grads(x, wt, stride, g, transposed=False):
+    x = x.clone().requires_grad_(True); wt = wt.clone().requires_grad_(True)
+    b = torch.zeros(wt.shape[1] if transposed else wt.shape[0], dtype=torch.float64, requires_grad=True)
+    if transposed:
+        y = F.conv_transpose2d(x, wt, b, stride=2, padding=1, output_padding=1)
+    else:
+        y = F.conv2d(x, wt, b, stride=stride, padding=(wt.shape[-1] - 1) // 2)
+    (y * g).sum().backward()
+    return x.grad, wt.grad, b.grad
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,h,w", [
+    (64, 64, 3, 1, 16, 32),
+    (31, 64, 9, 1, 16, 16),
+    (96, 64, 3, 1, 12, 20),
+    (64, 128, 3, 2, 32, 32),
+    (64, 64, 3, 2, 25, 26),
+    (64, 32, 3, 1, 16, 16),
+    (64, 1, 3, 1, 16, 16),
+    (192, 64, 1, 1, 8, 16),
+    (5, 32, 3, 1, 16, 16),
+])
+def test_conv2d_dgrad_wgrad(H, cin, cout, k, stride, h, w):
+    n = 2
+    pad = (k - 1) // 2
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    x = rnd(n, cin, h, w, seed=1); wt = rnd(cout, cin, k, k, seed=2, scale=0.1); g = rnd(n, cout, ho, wo, seed=3)
+    gx_ref, dw_ref, db_ref = _conv_grads(x, wt, stride, g)
+    gb = to_dev(H, g); wd = wt.float().cuda()
+    # dgrad in one piece, and (when cin splits into 2 sources) piecewise with accumulate + relu mask
+    gx = H.conv2d_dgrad(gb, cout, wd, 0, cin, k, stride, h, w)
+    close(from_dev(gx, cin), gx_ref)
+    y = rnd(n, cin, h, w, seed=4)
+    gx2 = torch.ones(n, h, w, (cin + 3) // 4 * 4, device="cuda")
+    gx2 = H.conv2d_dgrad(gb, cout, wd, 0, cin, k, stride, h, w, mask_y=to_dev(H, y), mask_mode=1, gx=gx2)
+    close(from_dev(gx2, cin), 1.0 + gx_ref * (y > 0))
+    if cin % 32 == 0 and cin >= 64:
+        half = cin // 2 if cin != 96 else 64
+        lo = H.conv2d_dgrad(gb, cout, wd, 0, half, k, stride, h, w)
+        hi = H.conv2d_dgrad(gb, cout, wd, half, cin - half, k, stride, h, w)
+        close(from_dev(lo, half), gx_ref[:, :half]); close(from_dev(hi, cin - half), gx_ref[:, half:])
+    # wgrad
+    dw, db = H.conv2d_wgrad((to_dev(H, x), (cin + 3) // 4 * 4, 0), h, w, gb, cout, k, stride, cin, 0)
+    torch.cuda.synchronize()
+    close(dw.double().cpu(), dw_ref); close(db.double().cpu(), db_ref)
+
+
+def test_conv2d_wgrad_concat_offset_and_upsample(H):
+    n, h, w = 2, 16, 16
+    a = rnd(n, 64, h, w, seed=1); c = rnd(n, 32, h, w, seed=2)
+    wt = rnd(64, 96, 3, 3, seed=3, scale=0.1); g = rnd(n, 64, h, w, seed=4)
+    _, dw_ref, db_ref = _conv_grads(torch.cat([a, c], 1), wt, 1, g)
+    gb = to_dev(H, g)
+    dw = torch.zeros(64, 96, 3, 3, device="cuda"); db = torch.zeros(64, device="cuda")
+    H.conv2d_wgrad((to_dev(H, a), 64, 0), h, w, gb, 64, 3, 1, 96, 0, dw=dw, db=db)
+    H.conv2d_wgrad((to_dev(H, c), 32, 0), h, w, gb, 64, 3, 1, 96, 64, dw=dw, db=None)
+    close(dw.double().cpu(), dw_ref); close(db.double().cpu(), db_ref)
+    lo = rnd(n, 64, 8, 8, seed=5)
+    up = F.interpolate(lo.float(), size=(16, 16), mode="nearest").double()
+    _, dw_ref, _ = _conv_grads(up, wt[:, :64].contiguous(), 1, g)
+    dw, _ = H.conv2d_wgrad((to_dev(H, lo), 64, 0), 16, 16, gb, 64, 3, 1, 64, 0)
+    close(dw.double().cpu(), dw_ref)
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(128, 64, 16, 16), (64, 64, 9, 20)])
+def test_conv_transpose2d_grads(H, cin, cout, h, w):
+    n = 2
+    x = rnd(n, cin, h, w, seed=1); wt = rnd(cin, cout, 3, 3, seed=2, scale=0.1); g = rnd(n, cout, 2 * h, 2 * w, seed=3)
+    gx_ref, dw_ref, db_ref = _conv_grads(x, wt, 2, g, transposed=True)
+    gb = to_dev(H, g)
+    gx = H.conv_transpose2d_dgrad(gb, wt.float().cuda())
+    close(from_dev(gx, cin), gx_ref)
+    dw, db = H.conv_transpose2d_wgrad(to_dev(H, x), gb, cin, cout)
+    close(dw.double().cpu(), dw_ref); close(db.double().cpu(), db_ref)
