@@ -87,6 +87,49 @@ int ssie_conv_transpose2d_wgrad(const ssie_src_t* x, int N, const float* g, int 
                                 float* dw, float* db, int accumulate,
                                 void* ws, size_t ws_bytes, void* stream);
 
+/* ---- plan executor: the whole hot path as a static launch schedule -----------------------------
+ * coefs8 = {c_loss_reconstruction, c_loss_r_fidelity, c_loss_i_smooth_low, c_loss_i_smooth_delta,
+ *           c_loss_fourier, c_loss_spectral_cons, alpha_i_smooth_low, alpha_i_smooth_delta}
+ * (LowLightEnhance.__init__ keywords, model.py:178-182).  H and W must be even (model.py:59) and >= 8.
+ * Returns NULL on an unsupported shape. */
+void* ssie_plan_create(int N, int bands, int H, int W, const float* coefs8);
+void ssie_plan_destroy(void* plan);
+size_t ssie_plan_workspace_bytes(void* plan);
+int ssie_plan_set_coefs(void* plan, const float* coefs8);
+
+/* flat parameter buffer layout = the reference's state_dict order (46 tensors, model.py:595-607);
+ * offsets in floats, each tensor 16-byte aligned */
+size_t ssie_plan_param_floats(void* plan);
+int ssie_plan_num_params(void* plan);
+int ssie_plan_param_info(void* plan, int idx, char* name, int name_cap, size_t* off_floats, int* ndim, int* shape4);
+
+/* named activation / gradient buffers inside the workspace (NHWC): dims5 = {N, H, W, C, cstride}.
+ * "RL_1" = sigmoid(recon): R_low = channels [0,bands), I_low = channel bands; "D" = I_delta; "S";
+ * "RL_2" = decomposition of S; "scalars" = {total, L_reconstruction, L_R_fidelity, L_I_smooth_low,
+ * L_I_smooth_delta, L_fourier, L_spectral_cons} (model.py:566-574) */
+int ssie_plan_buffer(void* plan, const char* name, size_t* off_floats, int* dims5);
+
+/* bind to caller-owned device memory (workspace 256-byte aligned; grads may be NULL for inference).
+ * Zeroes the workspace, uploads descriptors + the Fourier mask, synchronises `stream` once. */
+int ssie_plan_bind(void* plan, void* workspace, size_t ws_bytes, float* params, float* grads, void* stream);
+
+/* LowLightEnhance.forward (model.py:229-234): x is the logical (N,bands,H,W) fp32 tensor with element
+ * strides strides4 = {sN, sC, sH, sW} (channels_last or contiguous alike) */
+int ssie_plan_enhance_fwd(void* plan, const float* x, const long* strides4, void* stream);
+
+/* compute_loss (+ loss.backward() when with_backward != 0): model.py:544-575, :315.  Writes "scalars";
+ * with_backward also zeroes and fills the flat gradient buffer (zero_grad, model.py:313).
+ * The Fourier term needs power-of-two H, W with H*(W+1)*8 bytes <= 160 KiB LDS (SSIE_E_SHAPE otherwise). */
+int ssie_plan_loss_fwd_bwd(void* plan, const float* x, const long* strides4, int with_backward, void* stream);
+
+/* torch.optim.Adam.step with default hyper-parameters (model.py:213, :316) over flat buffers;
+ * grads are multiplied by grad_scale first (1/world_size after an all-reduce-sum) */
+int ssie_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n,
+                   float grad_scale, float lr, int step, float beta1, float beta2, float eps, void* stream);
+
+/* host helper: the reference's radial Fourier mask (model.py:460-464), float32-exact; out_host = H*W bytes */
+int ssie_fourier_mask(int H, int W, float cutoff, uint8_t* out_host);
+
 #ifdef __cplusplus
 }
 #endif

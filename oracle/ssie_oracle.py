@@ -130,7 +130,17 @@ def _conv(x, P, key, stride=1, relu=False):
     return F.relu(y) if relu else y
 
 
-def decomposition(P, x, pre="decomposition_net."):
+def _rec(tr, tag, **kw):
+    """record named intermediates (buffer names of the HIP plan) for stage-by-stage parity tests"""
+    if tr is None:
+        return
+    for k, v in kw.items():
+        if v.requires_grad:
+            v.retain_grad()
+        tr[k + tag] = v
+
+
+def decomposition(P, x, pre="decomposition_net.", tr=None, tag=""):
     """model.py:49-70 -> (R, L)"""
     bands = x.shape[1]
     c0 = _conv(x, P, pre + "conv0.0", relu=True)
@@ -143,10 +153,11 @@ def decomposition(P, x, pre="decomposition_net."):
     c5 = _conv(torch.cat([dc, c1], 1), P, pre + "conv5.0", relu=True)
     c7 = _conv(torch.cat([c5, c0], 1), P, pre + "conv7.0")
     c8 = _conv(c7, P, pre + "recon")
+    _rec(tr, tag, c0=c0, sh=sh, c1=c1, c2=c2, c3=c3, dc=dc, c5=c5, c7=c7, c8=c8)
     return torch.sigmoid(c8[:, :bands]), torch.sigmoid(c8[:, bands:])
 
 
-def attention_block(P, x, pre="illum_adjust_net.attn."):
+def attention_block(P, x, pre="illum_adjust_net.attn.", tr=None):
     """model.py:99-119; tokens = H*W, 4 heads x 16, no LayerNorm, residual on tokens."""
     n, c, h, w = x.shape
     s = h * w
@@ -156,7 +167,9 @@ def attention_block(P, x, pre="illum_adjust_net.attn."):
                for nm in ("q_linear", "k_linear", "v_linear"))
     att = torch.softmax(q @ k.transpose(-2, -1) / (HEAD_DIM ** 0.5), dim=-1)
     o = (att @ v).permute(0, 2, 1, 3).reshape(n, s, HEADS * HEAD_DIM)
-    ff = lin(F.relu(lin(o, "ff_linear1")), "ff_linear2")
+    f1 = F.relu(lin(o, "ff_linear1"))
+    ff = lin(f1, "ff_linear2")
+    _rec(tr, "", ao=o.permute(0, 2, 1).reshape(n, c, h, w), f1=f1.permute(0, 2, 1).reshape(n, c, h, w))
     return (tok + ff).permute(0, 2, 1).reshape(n, c, h, w)
 
 
@@ -164,25 +177,31 @@ def _up(x, like):
     return F.interpolate(x, size=like.shape[2:], mode="nearest")      # model.py:156,160,164,168,169
 
 
-def illum_adjust(P, I, R, pre="illum_adjust_net."):
+def illum_adjust(P, I, R, pre="illum_adjust_net.", tr=None):
     """model.py:143-175 -> I_delta (N,1,H,W); note cat order [R, I]."""
     c0 = _conv(torch.cat([R, I], 1), P, pre + "conv0.0")
     c1 = _conv(c0, P, pre + "conv1.0", stride=2, relu=True)
     c2 = _conv(c1, P, pre + "conv2.0", stride=2, relu=True)
     c3 = _conv(c2, P, pre + "conv3.0", stride=2, relu=True)
-    c3 = attention_block(P, c3, pre + "attn.")
-    d1 = _conv(_up(c3, c2), P, pre + "deconv1.0", relu=True) + c2
-    d2 = _conv(_up(d1, c1), P, pre + "deconv2.0", relu=True) + c1
-    d3 = _conv(_up(d2, c0), P, pre + "deconv3.0", relu=True) + c0
+    t3 = attention_block(P, c3, pre + "attn.", tr)
+    u1 = _conv(_up(t3, c2), P, pre + "deconv1.0", relu=True)
+    d1 = u1 + c2
+    u2 = _conv(_up(d1, c1), P, pre + "deconv2.0", relu=True)
+    d2 = u2 + c1
+    u3 = _conv(_up(d2, c0), P, pre + "deconv3.0", relu=True)
+    d3 = u3 + c0
     gather = torch.cat([_up(d1, d3), _up(d2, d3), d3], 1)
-    return _conv(_conv(gather, P, pre + "feature_fusion.0"), P, pre + "final_conv")
+    f = _conv(gather, P, pre + "feature_fusion.0")
+    _rec(tr, "", a0=c0, a1=c1, a2=c2, a3=c3, t3=t3, u1=u1, d1=d1, u2=u2, d2=d2, u3=u3, d3=d3, f=f)
+    return _conv(f, P, pre + "final_conv")
 
 
-def enhance_forward(P, x):
+def enhance_forward(P, x, tr=None):
     """model.py:229-234 -> (R_low, I_low, I_delta, S)"""
-    R, I = decomposition(P, x)
-    D = illum_adjust(P, I, R)
+    R, I = decomposition(P, x, tr=tr, tag="_1")
+    D = illum_adjust(P, I, R, tr=tr)
     S = R * D + R * I
+    _rec(tr, "", R=R, I=I, D=D, S=S)
     return R, I, D, S
 
 
@@ -231,20 +250,20 @@ def total_from_terms(terms, coefs):
             + coefs["c_id"] * l_id + coefs["c_f"] * l_f + coefs["c_sp"] * l_sp)      # :557-564
 
 
-def compute_loss(P, x, coefs):
+def compute_loss(P, x, coefs, tr=None):
     """model.py:544-575 -> (total 0-d tensor, dict of 7 floats, (R, I, D, S, E))."""
-    R, I, D, S = enhance_forward(P, x)
-    E, _ = decomposition(P, S)                                                           # :546
+    R, I, D, S = enhance_forward(P, x, tr)
+    E, _ = decomposition(P, S, tr=tr, tag="_2")                                          # :546
     terms = loss_terms(x, R, I, D, S, E, coefs)
     total = total_from_terms(terms, coefs)
     vals = dict(zip(LOSS_KEYS, [float(total.detach())] + [float(t.detach()) for t in terms]))
     return total, vals, (R, I, D, S, E)
 
 
-def loss_and_grads(P, x, coefs):
+def loss_and_grads(P, x, coefs, tr=None):
     """compute_loss + autograd backward (model.py:314-315) -> (loss dict, grads dict, outputs)."""
     Pg = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in P.items())
-    total, vals, outs = compute_loss(Pg, x, coefs)
+    total, vals, outs = compute_loss(Pg, x, coefs, tr)
     total.backward()
     grads = OrderedDict((k, (v.grad if v.grad is not None else torch.zeros_like(v))) for k, v in Pg.items())
     return vals, grads, tuple(o.detach() for o in outs)

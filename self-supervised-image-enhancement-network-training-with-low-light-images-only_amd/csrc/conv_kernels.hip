@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const ConvParams p)
             const size_t o = ((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.out_cstride + p.out_coff + co;
             float v = acc[m][r] + bv;
             if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-            else if (p.act == ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+            else if (p.act == ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
             if (p.mask_mode == MASK_RELU) v = p.mask_y[o] > 0.f ? v : 0.f;
             else if (p.mask_mode == MASK_SIGMOID) { float y = p.mask_y[o]; v *= y * (1.f - y); }
             if (p.out2) p.out2[o] = v;

@@ -1,0 +1,48 @@
+// Parameter blocks + host launchers of the HBM-bound loss / elementwise kernels.
+#pragma once
+#include "ssie_common.h"
+
+struct LossParams {
+    const float* x; int x_cs;        // input_low, NHWC padded
+    const float* RL; int rl_cs;      // pass-1 sigmoid output: R = ch [0,B), I_low = ch B
+    const float* D; int d_cs;        // I_delta at ch 0
+    const float* S; int s_cs;        // enhanced cube
+    const float* E; int e_cs;        // pass-2 sigmoid output (R_enh = ch [0,B))
+    float* gRL;                      // dL/d(R, I_low)           (geometry of RL)
+    float* gD;                       // dL/dI_delta              (geometry of D)
+    float* gS;                       // dL/dS direct terms       (geometry of S)
+    float* G8b;                      // dL/d(pre-sigmoid) of pass 2 (geometry of E)
+    int N, H, W, B;
+    float c_rec, c_rf, c_il, c_id, c_sp, a1, a2;
+    float inv_n0, inv_nIx, inv_nIy, inv_nRx, inv_nRy, inv_nsp;
+    float* partials;                 // [nblk][8]
+};
+
+struct FftParams {
+    const float* x; int x_cs;
+    const float* S; int s_cs;
+    float* gS;                       // += c_f * Re(H*W*ifft2(M * g_Z))
+    const uint8_t* mask;             // [H][W], unshifted layout (model.py:460-464)
+    int N, B, H, W, logH, logW;
+    float scale_g;                   // c_f / (N*B*H*W)
+    float inv_n0;
+    float* partials;                 // [gridDim.x]
+};
+
+int ssie_launch_loss_direct(const LossParams& p, int nblk, hipStream_t st);
+int ssie_launch_loss_finalize(const float* partials, int nblk, const float* fpartials, int nfblk,
+                              const float* coefs6, float* out, hipStream_t st);
+int ssie_launch_product_node(const float* gS, int s_cs, const float* RL, float* gRL, int rl_cs, const float* D, float* gD,
+                             int d_cs, long npix, int B, hipStream_t st);
+int ssie_launch_compose(const float* RL, int rl_cs, const float* D, int d_cs, float* S, int s_cs, long npix, int B, hipStream_t st);
+int ssie_launch_ingest(const float* x, long sn, long sc, long sh, long sw, float* out, int N, int C, int H, int W, int cs, hipStream_t st);
+int ssie_launch_mask_axpy(const float* src, int src_cs, const float* y, int y_cs, int mode, float* dst, int dst_cs,
+                          long npix, int C, int accumulate, hipStream_t st);
+int ssie_launch_upsample_adjoint(const float* src, int Hv, int Wv, int src_cs, float* dst, int Hs, int Ws, int dst_cs,
+                                 int N, int C, int accumulate, hipStream_t st);
+int ssie_launch_adam(float* p, const float* g, float* m, float* v, long n, float gscale, float lr, int step,
+                     float b1, float b2, float eps, hipStream_t st);
+int ssie_fft_supported(int H, int W);
+int ssie_fft_grid(int N, int B);
+int ssie_launch_fft_loss(const FftParams& p, hipStream_t st);
+void ssie_fourier_mask_host(int H, int W, float cutoff, uint8_t* out);

@@ -1,0 +1,657 @@
+// Plan executor: the whole hot path of the reference as a static schedule of HIP launches.
+//
+//   ssie_plan_enhance_fwd   == LowLightEnhance.forward            (/root/reference/model.py:229-234)
+//   ssie_plan_loss_fwd_bwd  == compute_loss + loss.backward()     (model.py:544-575, :315)
+//   ssie_adam_step          == torch.optim.Adam.step              (model.py:213, :316)
+//
+// A plan is built once per (N, bands, H, W); binding it to a caller-owned workspace and to the flat
+// parameter / gradient buffers materialises every launch descriptor, so a step is a fixed sequence of
+// kernel launches with no host-side shape logic, no allocation and no synchronisation.
+#include "layer_ops.h"
+#include "loss_kernels.h"
+#include "attention.h"
+#include "../../include/ssie_hip.h"
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+#include <string.h>
+#include <math.h>
+
+namespace {
+
+typedef std::function<int(hipStream_t)> Fn;
+
+struct ParamInfo { std::string name; size_t off; int shape[4]; int ndim; size_t numel; };
+struct BufInfo { size_t off; int N, H, W, C, cs; };
+struct LayerP { size_t w, b; int cout, cin, k; bool transposed; };
+
+const int CH = 64;
+const int kWgs = 512;
+
+struct Plan {
+    int N, B, H, W, CX, CRL;
+    int H2, W2, H4, W4, H8, W8;
+    std::vector<ParamInfo> params;
+    size_t nparam_floats = 0;
+    std::map<std::string, BufInfo> bufs;
+    size_t ws_floats = 0;
+    size_t slab_off = 0, slab_cap = 0, partial_off = 0, packdesc_off = 0, mask_off = 0, scal_off = 0;
+    size_t lpart_off = 0, fpart_off = 0;
+    int loss_blocks = 0, fft_blocks = 0;
+    float coefs[8];
+    // bound state
+    float* ws = nullptr; float* P = nullptr; float* G = nullptr;
+    std::vector<PackDesc> packs;
+    size_t pack_cursor = 0, pack_floats_total = 0, pack_off = 0;
+    std::vector<Fn> fwd, pass2, lossbwd;
+    bool bound = false;
+
+    float* buf(const char* n) { return ws + bufs.at(n).off; }
+    const BufInfo& bi(const char* n) { return bufs.at(n); }
+};
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+void add_param(Plan& pl, const std::string& name, int d0, int d1 = 0, int d2 = 0, int d3 = 0)
+{
+    ParamInfo pi; pi.name = name; pi.off = pl.nparam_floats;
+    pi.shape[0] = d0; pi.shape[1] = d1; pi.shape[2] = d2; pi.shape[3] = d3;
+    pi.ndim = d3 ? 4 : (d1 ? 2 : 1);
+    pi.numel = (size_t)d0 * (d1 ? d1 : 1) * (d2 ? d2 : 1) * (d3 ? d3 : 1);
+    pl.nparam_floats = align_up(pl.nparam_floats + pi.numel, 4);
+    pl.params.push_back(pi);
+}
+
+// state-dict order of the reference module (model.py:33-47, 93-97, 125-141)
+void build_params(Plan& pl)
+{
+    const int B = pl.B, c = CH;
+    auto cw = [&](const std::string& n, int co, int ci, int k) { add_param(pl, n + ".weight", co, ci, k, k); add_param(pl, n + ".bias", co); };
+    const std::string d = "decomposition_net.", i = "illum_adjust_net.";
+    cw(d + "conv0.0", c / 2, B, 3); cw(d + "shallow_conv.0", c, B, 9); cw(d + "conv1.0", c, c, 3);
+    cw(d + "conv2.0", 2 * c, c, 3); cw(d + "conv3.0", 2 * c, 2 * c, 3);
+    add_param(pl, d + "deconv.0.weight", 2 * c, c, 3, 3); add_param(pl, d + "deconv.0.bias", c);
+    cw(d + "conv5.0", c, 2 * c, 3); cw(d + "conv7.0", c, c + c / 2, 3); cw(d + "recon", B + 1, c, 3);
+    cw(i + "conv0.0", c, B + 1, 3); cw(i + "conv1.0", c, c, 3); cw(i + "conv2.0", c, c, 3); cw(i + "conv3.0", c, c, 3);
+    const char* lin[5] = {"q_linear", "k_linear", "v_linear", "ff_linear1", "ff_linear2"};
+    for (int q = 0; q < 5; ++q) { add_param(pl, i + "attn." + lin[q] + ".weight", 64, 64); add_param(pl, i + "attn." + lin[q] + ".bias", 64); }
+    cw(i + "deconv1.0", c, c, 3); cw(i + "deconv2.0", c, c, 3); cw(i + "deconv3.0", c, c, 3);
+    cw(i + "feature_fusion.0", c, 3 * c, 1); cw(i + "final_conv", 1, c, 3);
+}
+
+LayerP layer(Plan& pl, const std::string& name, bool transposed = false)
+{
+    LayerP L; memset(&L, 0, sizeof(L));
+    for (size_t q = 0; q < pl.params.size(); ++q) {
+        if (pl.params[q].name == name + ".weight") {
+            const ParamInfo& w = pl.params[q];
+            L.w = w.off; L.b = pl.params[q + 1].off; L.transposed = transposed;
+            L.k = w.ndim == 4 ? w.shape[2] : 1;
+            if (transposed) { L.cin = w.shape[0]; L.cout = w.shape[1]; } else { L.cout = w.shape[0]; L.cin = w.shape[1]; }
+            return L;
+        }
+    }
+    return L;
+}
+
+size_t alloc(Plan& pl, const char* name, int N, int H, int W, int C)
+{
+    BufInfo b; b.off = pl.ws_floats; b.N = N; b.H = H; b.W = W; b.C = C; b.cs = ssie_round_up(C, 4);
+    pl.ws_floats = align_up(pl.ws_floats + (size_t)N * H * W * b.cs, 64);
+    pl.bufs[name] = b;
+    return b.off;
+}
+
+void build_buffers(Plan& pl)
+{
+    const int N = pl.N, H = pl.H, W = pl.W, B = pl.B;
+    const int H2 = pl.H2, W2 = pl.W2, H4 = pl.H4, W4 = pl.W4, H8 = pl.H8, W8 = pl.W8;
+    alloc(pl, "x", N, H, W, B); alloc(pl, "S", N, H, W, B); alloc(pl, "gS", N, H, W, B);
+    alloc(pl, "D", N, H, W, 1); alloc(pl, "gD", N, H, W, 1);
+    alloc(pl, "gRL", N, H, W, B + 1);
+    for (int p = 1; p <= 2; ++p) {
+        auto nm = [&](const char* s) { return std::string(s) + (p == 1 ? "_1" : "_2"); };
+        alloc(pl, nm("c0").c_str(), N, H, W, 32); alloc(pl, nm("sh").c_str(), N, H, W, 64);
+        alloc(pl, nm("c1").c_str(), N, H, W, 64); alloc(pl, nm("c2").c_str(), N, H2, W2, 128);
+        alloc(pl, nm("c3").c_str(), N, H2, W2, 128); alloc(pl, nm("dc").c_str(), N, H, W, 64);
+        alloc(pl, nm("c5").c_str(), N, H, W, 64); alloc(pl, nm("c7").c_str(), N, H, W, 64);
+        alloc(pl, nm("RL").c_str(), N, H, W, B + 1);
+    }
+    // decomposition gradients (w.r.t. pre-activation), shared by both backward passes
+    alloc(pl, "G8", N, H, W, B + 1); alloc(pl, "G7", N, H, W, 64); alloc(pl, "G5", N, H, W, 64); alloc(pl, "G0", N, H, W, 32);
+    alloc(pl, "Gdc", N, H, W, 64); alloc(pl, "G3", N, H2, W2, 128); alloc(pl, "G2", N, H2, W2, 128);
+    alloc(pl, "G1", N, H, W, 64); alloc(pl, "Gsh", N, H, W, 64);
+    // illumination net
+    alloc(pl, "a0", N, H, W, 64); alloc(pl, "a1", N, H2, W2, 64); alloc(pl, "a2", N, H4, W4, 64); alloc(pl, "a3", N, H8, W8, 64);
+    alloc(pl, "qkv", N, H8, W8, 192); alloc(pl, "ao", N, H8, W8, 64); alloc(pl, "f1", N, H8, W8, 64); alloc(pl, "t3", N, H8, W8, 64);
+    alloc(pl, "lse", N, 4, H8 * W8, 1); alloc(pl, "delta", N, 4, H8 * W8, 1);
+    alloc(pl, "u1", N, H4, W4, 64); alloc(pl, "d1", N, H4, W4, 64); alloc(pl, "u2", N, H2, W2, 64); alloc(pl, "d2", N, H2, W2, 64);
+    alloc(pl, "u3", N, H, W, 64); alloc(pl, "d3", N, H, W, 64); alloc(pl, "f", N, H, W, 64);
+    alloc(pl, "Gf", N, H, W, 64); alloc(pl, "gd3", N, H, W, 64); alloc(pl, "Ge3", N, H, W, 64); alloc(pl, "tmpH", N, H, W, 64);
+    alloc(pl, "gd2", N, H2, W2, 64); alloc(pl, "Ge2", N, H2, W2, 64); alloc(pl, "gd1", N, H4, W4, 64); alloc(pl, "Ge1", N, H4, W4, 64);
+    alloc(pl, "gt3", N, H8, W8, 64); alloc(pl, "gf1", N, H8, W8, 64); alloc(pl, "gao", N, H8, W8, 64); alloc(pl, "gqkv", N, H8, W8, 192);
+    // scratch
+    pl.slab_cap = (size_t)kWgs * 9 * 64 * 64 + (size_t)81 * ssie_round_up(B + 1, 64) * 128;
+    pl.slab_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + pl.slab_cap, 64);
+    pl.partial_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 256 * 256, 64);
+    pl.loss_blocks = 2048; pl.fft_blocks = ssie_fft_grid(N, B);
+    pl.lpart_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + (size_t)pl.loss_blocks * 8, 64);
+    pl.fpart_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + (size_t)pl.fft_blocks, 64);
+    pl.scal_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 16, 64);
+    pl.mask_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + ((size_t)H * W + 3) / 4, 64);
+    pl.packdesc_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 256 * sizeof(PackDesc) / 4, 64);
+    pl.pack_off = pl.ws_floats;     // packed weights grow from here at bind time (size known after a dry build)
+}
+
+// -------------------------------------------------------------------------------------------------
+struct Builder {
+    Plan& pl;
+    bool dry;                 // dry run: only count packed-weight floats
+    explicit Builder(Plan& p, bool d) : pl(p), dry(d) { pl.pack_cursor = 0; pl.packs.clear(); }
+
+    float* take_pack(size_t floats)
+    {
+        float* r = dry ? nullptr : pl.ws + pl.pack_off + pl.pack_cursor;
+        pl.pack_cursor = align_up(pl.pack_cursor + floats, 64);
+        return r;
+    }
+    SrcDesc src(const char* name, int C, int Hv, int Wv, int coff = 0)
+    {
+        const BufInfo& b = pl.bi(name);
+        return ssie_make_src(dry ? nullptr : pl.buf(name), C, b.cs, coff, b.H, b.W, Hv, Wv);
+    }
+    float* ptr(const char* name) { return dry ? nullptr : pl.buf(name); }
+    float* par(size_t off) { return dry ? nullptr : pl.P + off; }
+    float* grad(size_t off) { return dry ? nullptr : pl.G + off; }
+    void push(std::vector<Fn>& ops, const ConvParams& p) { if (!dry) ops.push_back([p](hipStream_t st) { return ssie_launch_fprop(p, st); }); }
+
+    // forward conv (stride 1/2) over concatenated / up-sampled sources
+    int conv(std::vector<Fn>& ops, const LayerP& L, std::vector<SrcDesc> srcs, int Hv, int Wv, int stride,
+             const char* out, int act, const char* addsrc = nullptr, const char* out2 = nullptr, int out_coff = 0)
+    {
+        const int T = L.k * L.k, pad = (L.k - 1) / 2;
+        TapList t = ssie_taps_conv(L.k);
+        float* wp = take_pack(ssie_packed_floats(L.cin, L.cout, T));
+        if (dry) return 0;
+        pl.packs.push_back(ssie_make_pack(pl.P + L.w, wp, L.cin, L.cout, t, T, L.cin * T, 1));
+        const BufInfo& ob = pl.bi(out);
+        Epilogue e; memset(&e, 0, sizeof(e)); e.bias = pl.P + L.b; e.act = act;
+        e.addsrc = addsrc ? pl.buf(addsrc) : nullptr; e.out2 = out2 ? pl.buf(out2) : nullptr;
+        const int Ho = (Hv + 2 * pad - L.k) / stride + 1, Wo = (Wv + 2 * pad - L.k) / stride + 1;
+        if (Ho != ob.H || Wo != ob.W) return SSIE_E_SHAPE;
+        ConvParams p;
+        int rc = ssie_make_conv(p, srcs.data(), (int)srcs.size(), pl.N, Hv, Wv, t, stride, Ho, Wo, wp, L.cout,
+                                pl.buf(out), ob.H, ob.W, ob.cs, out_coff, 1, 0, 0, e);
+        if (rc) return rc;
+        push(ops, p);
+        return 0;
+    }
+
+    // transposed-conv machinery: ConvTranspose2d forward (weight (in,out,3,3)) and dgrad of a stride-2 conv (OIHW)
+    int transposed(std::vector<Fn>& ops, const float* wbase, int Kc, int Nc, int s_k, int s_n, SrcDesc in, int Hin, int Win,
+                   const char* out, const Epilogue& e)
+    {
+        const BufInfo& ob = pl.bi(out);
+        for (int py = 0; py < 2; ++py) for (int px = 0; px < 2; ++px) {
+            TapList t = ssie_taps_transposed(3, 1, py, px);
+            float* wp = take_pack(ssie_packed_floats(Kc, Nc, t.n));
+            if (dry) continue;
+            pl.packs.push_back(ssie_make_pack(wbase, wp, Kc, Nc, t, s_k, s_n, 1));
+            ConvParams p;
+            const int Ho = ssie_ceil_div(ob.H - py, 2), Wo = ssie_ceil_div(ob.W - px, 2);
+            int rc = ssie_make_conv(p, &in, 1, pl.N, Hin, Win, t, 1, Ho, Wo, wp, Nc, pl.buf(out), ob.H, ob.W, ob.cs, 0, 2, py, px, e);
+            if (rc) return rc;
+            push(ops, p);
+        }
+        return 0;
+    }
+
+    Epilogue bwd_epi(const char* mask_y, int mask_mode, int accumulate)
+    {
+        Epilogue e; memset(&e, 0, sizeof(e));
+        e.mask_y = (mask_y && !dry) ? pl.buf(mask_y) : nullptr; e.mask_mode = mask_y ? mask_mode : 0; e.accumulate = accumulate;
+        return e;
+    }
+
+    // data gradient of a forward conv layer w.r.t. input channels [ci_off, ci_off + cs)
+    int dgrad(std::vector<Fn>& ops, const LayerP& L, int stride, const char* g, int g_coff, int ci_off, int cs,
+              const char* gx, const char* mask_y, int mask_mode, int accumulate)
+    {
+        const int T = L.k * L.k;
+        const BufInfo& gb = pl.bi(g); const BufInfo& xb = pl.bi(gx);
+        SrcDesc in = ssie_make_src(ptr(g), ssie_round_up(L.cout, 4), gb.cs, g_coff, gb.H, gb.W, gb.H, gb.W);
+        Epilogue e = bwd_epi(mask_y, mask_mode, accumulate);
+        const float* wbase = dry ? nullptr : pl.P + L.w + (size_t)ci_off * T;
+        if (stride == 1) {
+            TapList t = ssie_taps_dgrad_s1(L.k);
+            float* wp = take_pack(ssie_packed_floats(L.cout, cs, T));
+            if (dry) return 0;
+            pl.packs.push_back(ssie_make_pack(wbase, wp, L.cout, cs, t, L.cin * T, T, 1));
+            ConvParams p;
+            int rc = ssie_make_conv(p, &in, 1, pl.N, gb.H, gb.W, t, 1, xb.H, xb.W, wp, cs, pl.buf(gx), xb.H, xb.W, xb.cs, 0, 1, 0, 0, e);
+            if (rc) return rc;
+            push(ops, p);
+            return 0;
+        }
+        return transposed(ops, wbase, L.cout, cs, L.cin * T, T, in, gb.H, gb.W, gx, e);
+    }
+
+    int wgrad(std::vector<Fn>& ops, const LayerP& L, int stride, SrcDesc x, int creal, int Hv, int Wv, int ci_off, const char* g, int g_coff = 0)
+    {
+        if (dry) return 0;
+        const int T = L.k * L.k, pad = (L.k - 1) / 2;
+        const BufInfo& gb = pl.bi(g);
+        const int Ho = (Hv + 2 * pad - L.k) / stride + 1, Wo = (Wv + 2 * pad - L.k) / stride + 1;
+        if (Ho != gb.H || Wo != gb.W) return SSIE_E_SHAPE;
+        TapList t = ssie_taps_conv(L.k);
+        WgradParams p;
+        int rc = ssie_make_wgrad(p, x, pl.N, Hv, Wv, 0, pl.buf(g), gb.cs, g_coff, L.cout, Ho, Wo, stride, t, pl.ws + pl.slab_off, kWgs);
+        if (rc) return rc;
+        if (ssie_wgrad_slab_floats(p) > pl.slab_cap) return SSIE_E_WORKSPACE;
+        float* dw = pl.G + L.w + (size_t)ci_off * T;
+        const long s_co = (long)L.cin * T;
+        const float* slabs = pl.ws + pl.slab_off;
+        const int cout = L.cout;
+        ops.push_back([p](hipStream_t st) { return ssie_launch_wgrad(p, st); });
+        ops.push_back([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, p.nslices, p.ntaps, p.ci_pad, p.co_pad, creal, cout, dw, s_co, T, 1, 1, st); });
+        return 0;
+    }
+
+    void bias_grad(std::vector<Fn>& ops, const LayerP& L, const char* g, int g_coff = 0)
+    {
+        if (dry) return;
+        const BufInfo& gb = pl.bi(g);
+        const float* gp = pl.buf(g); float* part = pl.ws + pl.partial_off; float* db = pl.G + L.b;
+        const long npix = (long)gb.N * gb.H * gb.W; const int cs = gb.cs, C = L.cout;
+        ops.push_back([=](hipStream_t st) { return ssie_launch_colsum(gp, npix, cs, g_coff, C, part, 256, db, 1, st); });
+    }
+
+    void mask_axpy(std::vector<Fn>& ops, const char* src, const char* y, int mode, const char* dst, int C, int accumulate)
+    {
+        if (dry) return;
+        const BufInfo& sb = pl.bi(src); const BufInfo& db = pl.bi(dst);
+        const float* sp = pl.buf(src); const float* yp = y ? pl.buf(y) : nullptr; float* dp = pl.buf(dst);
+        const int ycs = y ? pl.bi(y).cs : 0, scs = sb.cs, dcs = db.cs;
+        const long npix = (long)sb.N * sb.H * sb.W;
+        ops.push_back([=](hipStream_t st) { return ssie_launch_mask_axpy(sp, scs, yp, ycs, mode, dp, dcs, npix, C, accumulate, st); });
+    }
+
+    void upadj(std::vector<Fn>& ops, const char* src, int Hv, int Wv, const char* dst, int accumulate)
+    {
+        if (dry) return;
+        const BufInfo& db = pl.bi(dst);
+        const float* sp = pl.buf(src); float* dp = pl.buf(dst);
+        const int scs = pl.bi(src).cs, dcs = db.cs, Hs = db.H, Ws = db.W, N = pl.N;
+        ops.push_back([=](hipStream_t st) { return ssie_launch_upsample_adjoint(sp, Hv, Wv, scs, dp, Hs, Ws, dcs, N, 64, accumulate, st); });
+    }
+};
+
+#define CK(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+
+int build_decomposition_fwd(Builder& b, std::vector<Fn>& ops, const char* xin, int p)
+{
+    Plan& pl = b.pl;
+    const int H = pl.H, W = pl.W, H2 = pl.H2, W2 = pl.W2;
+    auto nm = [&](const char* s) { return std::string(s) + (p == 1 ? "_1" : "_2"); };
+    const std::string c0 = nm("c0"), sh = nm("sh"), c1 = nm("c1"), c2 = nm("c2"), c3 = nm("c3"), dc = nm("dc"), c5 = nm("c5"), c7 = nm("c7"), RL = nm("RL");
+    const std::string d = "decomposition_net.";
+    CK(b.conv(ops, layer(pl, d + "conv0.0"), {b.src(xin, pl.CX, H, W)}, H, W, 1, c0.c_str(), ACT_RELU));
+    CK(b.conv(ops, layer(pl, d + "shallow_conv.0"), {b.src(xin, pl.CX, H, W)}, H, W, 1, sh.c_str(), ACT_NONE));
+    CK(b.conv(ops, layer(pl, d + "conv1.0"), {b.src(sh.c_str(), 64, H, W)}, H, W, 1, c1.c_str(), ACT_RELU));
+    CK(b.conv(ops, layer(pl, d + "conv2.0"), {b.src(c1.c_str(), 64, H, W)}, H, W, 2, c2.c_str(), ACT_RELU));
+    CK(b.conv(ops, layer(pl, d + "conv3.0"), {b.src(c2.c_str(), 128, H2, W2)}, H2, W2, 1, c3.c_str(), ACT_RELU));
+    {
+        LayerP L = layer(pl, d + "deconv.0", true);
+        Epilogue e; memset(&e, 0, sizeof(e)); e.bias = b.par(L.b); e.act = ACT_RELU;
+        CK(b.transposed(ops, b.par(L.w), L.cin, L.cout, L.cout * 9, 9, b.src(c3.c_str(), 128, H2, W2), H2, W2, dc.c_str(), e));
+    }
+    CK(b.conv(ops, layer(pl, d + "conv5.0"), {b.src(dc.c_str(), 64, H, W), b.src(c1.c_str(), 64, H, W)}, H, W, 1, c5.c_str(), ACT_RELU));
+    CK(b.conv(ops, layer(pl, d + "conv7.0"), {b.src(c5.c_str(), 64, H, W), b.src(c0.c_str(), 32, H, W)}, H, W, 1, c7.c_str(), ACT_NONE));
+    CK(b.conv(ops, layer(pl, d + "recon"), {b.src(c7.c_str(), 64, H, W)}, H, W, 1, RL.c_str(), ACT_SIGMOID));
+    return 0;
+}
+
+int build_illum_fwd(Builder& b, std::vector<Fn>& ops)
+{
+    Plan& pl = b.pl;
+    const int H = pl.H, W = pl.W, H2 = pl.H2, W2 = pl.W2, H4 = pl.H4, W4 = pl.W4, H8 = pl.H8, W8 = pl.W8;
+    const std::string i = "illum_adjust_net.";
+    CK(b.conv(ops, layer(pl, i + "conv0.0"), {b.src("RL_1", pl.CRL, H, W)}, H, W, 1, "a0", ACT_NONE));
+    CK(b.conv(ops, layer(pl, i + "conv1.0"), {b.src("a0", 64, H, W)}, H, W, 2, "a1", ACT_RELU));
+    CK(b.conv(ops, layer(pl, i + "conv2.0"), {b.src("a1", 64, H2, W2)}, H2, W2, 2, "a2", ACT_RELU));
+    CK(b.conv(ops, layer(pl, i + "conv3.0"), {b.src("a2", 64, H4, W4)}, H4, W4, 2, "a3", ACT_RELU));
+    // TransformerBlock (model.py:99-119): tokens = NHWC pixels of a3
+    CK(b.conv(ops, layer(pl, i + "attn.q_linear"), {b.src("a3", 64, H8, W8)}, H8, W8, 1, "qkv", ACT_NONE, nullptr, nullptr, 0));
+    CK(b.conv(ops, layer(pl, i + "attn.k_linear"), {b.src("a3", 64, H8, W8)}, H8, W8, 1, "qkv", ACT_NONE, nullptr, nullptr, 64));
+    CK(b.conv(ops, layer(pl, i + "attn.v_linear"), {b.src("a3", 64, H8, W8)}, H8, W8, 1, "qkv", ACT_NONE, nullptr, nullptr, 128));
+    if (!b.dry) {
+        const float* qkv = pl.buf("qkv"); float* ao = pl.buf("ao"); float* lse = pl.buf("lse");
+        const int N = pl.N, T = H8 * W8;
+        ops.push_back([=](hipStream_t st) { return ssie_launch_attn_fwd(qkv, 192, ao, 64, lse, N, T, st); });
+    }
+    CK(b.conv(ops, layer(pl, i + "attn.ff_linear1"), {b.src("ao", 64, H8, W8)}, H8, W8, 1, "f1", ACT_RELU));
+    CK(b.conv(ops, layer(pl, i + "attn.ff_linear2"), {b.src("f1", 64, H8, W8)}, H8, W8, 1, "t3", ACT_NONE, "a3"));
+    CK(b.conv(ops, layer(pl, i + "deconv1.0"), {b.src("t3", 64, H4, W4)}, H4, W4, 1, "d1", ACT_RELU, "a2", "u1"));
+    CK(b.conv(ops, layer(pl, i + "deconv2.0"), {b.src("d1", 64, H2, W2)}, H2, W2, 1, "d2", ACT_RELU, "a1", "u2"));
+    CK(b.conv(ops, layer(pl, i + "deconv3.0"), {b.src("d2", 64, H, W)}, H, W, 1, "d3", ACT_RELU, "a0", "u3"));
+    CK(b.conv(ops, layer(pl, i + "feature_fusion.0"), {b.src("d1", 64, H, W), b.src("d2", 64, H, W), b.src("d3", 64, H, W)}, H, W, 1, "f", ACT_NONE));
+    CK(b.conv(ops, layer(pl, i + "final_conv"), {b.src("f", 64, H, W)}, H, W, 1, "D", ACT_NONE));
+    if (!b.dry) {
+        const float* RL = pl.buf("RL_1"); const float* D = pl.buf("D"); float* S = pl.buf("S");
+        const int rl = pl.CRL, cx = pl.CX, B = pl.B; const long npix = (long)pl.N * H * W;
+        ops.push_back([=](hipStream_t st) { return ssie_launch_compose(RL, rl, D, 4, S, cx, npix, B, st); });
+    }
+    return 0;
+}
+
+// backward of one decomposition pass; G8 holds dL/d(pre-sigmoid recon output)
+int build_decomposition_bwd(Builder& b, std::vector<Fn>& ops, const char* xin, int p, bool input_grad)
+{
+    Plan& pl = b.pl;
+    const int H = pl.H, W = pl.W, H2 = pl.H2, W2 = pl.W2;
+    auto nm = [&](const char* s) { return std::string(s) + (p == 1 ? "_1" : "_2"); };
+    const std::string c0 = nm("c0"), sh = nm("sh"), c1 = nm("c1"), c2 = nm("c2"), c3 = nm("c3"), dc = nm("dc"), c5 = nm("c5"), c7 = nm("c7");
+    const std::string d = "decomposition_net.";
+    const LayerP Lr = layer(pl, d + "recon"), L7 = layer(pl, d + "conv7.0"), L5 = layer(pl, d + "conv5.0"), Ld = layer(pl, d + "deconv.0", true),
+                 L3 = layer(pl, d + "conv3.0"), L2 = layer(pl, d + "conv2.0"), L1 = layer(pl, d + "conv1.0"), Ls = layer(pl, d + "shallow_conv.0"),
+                 L0 = layer(pl, d + "conv0.0");
+    CK(b.wgrad(ops, Lr, 1, b.src(c7.c_str(), 64, H, W), 64, H, W, 0, "G8")); b.bias_grad(ops, Lr, "G8");
+    CK(b.dgrad(ops, Lr, 1, "G8", 0, 0, 64, "G7", nullptr, 0, 0));
+    CK(b.wgrad(ops, L7, 1, b.src(c5.c_str(), 64, H, W), 64, H, W, 0, "G7"));
+    CK(b.wgrad(ops, L7, 1, b.src(c0.c_str(), 32, H, W), 32, H, W, 64, "G7")); b.bias_grad(ops, L7, "G7");
+    CK(b.dgrad(ops, L7, 1, "G7", 0, 0, 64, "G5", c5.c_str(), MASK_RELU, 0));
+    CK(b.dgrad(ops, L7, 1, "G7", 0, 64, 32, "G0", c0.c_str(), MASK_RELU, 0));
+    CK(b.wgrad(ops, L5, 1, b.src(dc.c_str(), 64, H, W), 64, H, W, 0, "G5"));
+    CK(b.wgrad(ops, L5, 1, b.src(c1.c_str(), 64, H, W), 64, H, W, 64, "G5")); b.bias_grad(ops, L5, "G5");
+    CK(b.dgrad(ops, L5, 1, "G5", 0, 0, 64, "Gdc", dc.c_str(), MASK_RELU, 0));
+    CK(b.dgrad(ops, L5, 1, "G5", 0, 64, 64, "G1", c1.c_str(), MASK_RELU, 0));
+    // ConvTranspose2d: wgrad with swapped roles, dgrad = stride-2 conv of Gdc with W read as OIHW (O = ci, I = co)
+    if (!b.dry) {
+        SrcDesc gs = b.src("Gdc", 64, H, W);
+        WgradParams wp; TapList t = ssie_taps_conv(3);
+        const BufInfo& cb = pl.bi(c3.c_str());
+        CK(ssie_make_wgrad(wp, gs, pl.N, H, W, 0, pl.buf(c3.c_str()), cb.cs, 0, 128, H2, W2, 2, t, pl.ws + pl.slab_off, kWgs));
+        if (ssie_wgrad_slab_floats(wp) > pl.slab_cap) return SSIE_E_WORKSPACE;
+        float* dw = pl.G + Ld.w; const float* slabs = pl.ws + pl.slab_off;
+        ops.push_back([wp](hipStream_t st) { return ssie_launch_wgrad(wp, st); });
+        ops.push_back([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, wp.nslices, wp.ntaps, wp.ci_pad, wp.co_pad, 64, 128, dw, 64L * 9, 9, 1, 1, st); });
+    }
+    b.bias_grad(ops, Ld, "Gdc");
+    {
+        TapList t = ssie_taps_conv(3);
+        float* wpk = b.take_pack(ssie_packed_floats(64, 128, 9));
+        if (!b.dry) {
+            pl.packs.push_back(ssie_make_pack(pl.P + Ld.w, wpk, 64, 128, t, 9, 64 * 9, 1));
+            SrcDesc in = b.src("Gdc", 64, H, W);
+            Epilogue e = b.bwd_epi(c3.c_str(), MASK_RELU, 0);
+            ConvParams cp; const BufInfo& ob = pl.bi("G3");
+            CK(ssie_make_conv(cp, &in, 1, pl.N, H, W, t, 2, H2, W2, wpk, 128, pl.buf("G3"), ob.H, ob.W, ob.cs, 0, 1, 0, 0, e));
+            b.push(ops, cp);
+        }
+    }
+    CK(b.wgrad(ops, L3, 1, b.src(c2.c_str(), 128, H2, W2), 128, H2, W2, 0, "G3")); b.bias_grad(ops, L3, "G3");
+    CK(b.dgrad(ops, L3, 1, "G3", 0, 0, 128, "G2", c2.c_str(), MASK_RELU, 0));
+    CK(b.wgrad(ops, L2, 2, b.src(c1.c_str(), 64, H, W), 64, H, W, 0, "G2")); b.bias_grad(ops, L2, "G2");
+    CK(b.dgrad(ops, L2, 2, "G2", 0, 0, 64, "G1", c1.c_str(), MASK_RELU, 1));
+    CK(b.wgrad(ops, L1, 1, b.src(sh.c_str(), 64, H, W), 64, H, W, 0, "G1")); b.bias_grad(ops, L1, "G1");
+    CK(b.dgrad(ops, L1, 1, "G1", 0, 0, 64, "Gsh", nullptr, 0, 0));
+    CK(b.wgrad(ops, Ls, 1, b.src(xin, pl.CX, H, W), pl.B, H, W, 0, "Gsh")); b.bias_grad(ops, Ls, "Gsh");
+    CK(b.wgrad(ops, L0, 1, b.src(xin, pl.CX, H, W), pl.B, H, W, 0, "G0")); b.bias_grad(ops, L0, "G0");
+    if (input_grad) {
+        CK(b.dgrad(ops, Ls, 1, "Gsh", 0, 0, pl.B, "gS", nullptr, 0, 1));
+        CK(b.dgrad(ops, L0, 1, "G0", 0, 0, pl.B, "gS", nullptr, 0, 1));
+    }
+    return 0;
+}
+
+int build_illum_bwd(Builder& b, std::vector<Fn>& ops)
+{
+    Plan& pl = b.pl;
+    const int H = pl.H, W = pl.W, H2 = pl.H2, W2 = pl.W2, H4 = pl.H4, W4 = pl.W4, H8 = pl.H8, W8 = pl.W8;
+    const std::string i = "illum_adjust_net.";
+    const LayerP Lf = layer(pl, i + "final_conv"), Lu = layer(pl, i + "feature_fusion.0"), Ld3 = layer(pl, i + "deconv3.0"),
+                 Ld2 = layer(pl, i + "deconv2.0"), Ld1 = layer(pl, i + "deconv1.0"), Lff2 = layer(pl, i + "attn.ff_linear2"),
+                 Lff1 = layer(pl, i + "attn.ff_linear1"), Lq = layer(pl, i + "attn.q_linear"), Lk = layer(pl, i + "attn.k_linear"),
+                 Lv = layer(pl, i + "attn.v_linear"), Lc3 = layer(pl, i + "conv3.0"), Lc2 = layer(pl, i + "conv2.0"),
+                 Lc1 = layer(pl, i + "conv1.0"), Lc0 = layer(pl, i + "conv0.0");
+    CK(b.wgrad(ops, Lf, 1, b.src("f", 64, H, W), 64, H, W, 0, "gD")); b.bias_grad(ops, Lf, "gD");
+    CK(b.dgrad(ops, Lf, 1, "gD", 0, 0, 64, "Gf", nullptr, 0, 0));
+    CK(b.wgrad(ops, Lu, 1, b.src("d1", 64, H, W), 64, H, W, 0, "Gf"));
+    CK(b.wgrad(ops, Lu, 1, b.src("d2", 64, H, W), 64, H, W, 64, "Gf"));
+    CK(b.wgrad(ops, Lu, 1, b.src("d3", 64, H, W), 64, H, W, 128, "Gf")); b.bias_grad(ops, Lu, "Gf");
+    CK(b.dgrad(ops, Lu, 1, "Gf", 0, 128, 64, "gd3", nullptr, 0, 0));
+    CK(b.dgrad(ops, Lu, 1, "Gf", 0, 64, 64, "tmpH", nullptr, 0, 0)); b.upadj(ops, "tmpH", H, W, "gd2", 0);
+    CK(b.dgrad(ops, Lu, 1, "Gf", 0, 0, 64, "tmpH", nullptr, 0, 0)); b.upadj(ops, "tmpH", H, W, "gd1", 0);
+    // level H: d3 = relu(e3) + a0
+    b.mask_axpy(ops, "gd3", "u3", MASK_RELU, "Ge3", 64, 0);
+    CK(b.wgrad(ops, Ld3, 1, b.src("d2", 64, H, W), 64, H, W, 0, "Ge3")); b.bias_grad(ops, Ld3, "Ge3");
+    CK(b.dgrad(ops, Ld3, 1, "Ge3", 0, 0, 64, "tmpH", nullptr, 0, 0)); b.upadj(ops, "tmpH", H, W, "gd2", 1);
+    // level H/2: d2 = relu(e2) + a1.  tmpH is reused with the (H2, W2) geometry through a view buffer
+    b.mask_axpy(ops, "gd2", "u2", MASK_RELU, "Ge2", 64, 0);
+    CK(b.wgrad(ops, Ld2, 1, b.src("d1", 64, H2, W2), 64, H2, W2, 0, "Ge2")); b.bias_grad(ops, Ld2, "Ge2");
+    CK(b.dgrad(ops, Ld2, 1, "Ge2", 0, 0, 64, "tmpH2", nullptr, 0, 0)); b.upadj(ops, "tmpH2", H2, W2, "gd1", 1);
+    // level H/4
+    b.mask_axpy(ops, "gd1", "u1", MASK_RELU, "Ge1", 64, 0);
+    CK(b.wgrad(ops, Ld1, 1, b.src("t3", 64, H4, W4), 64, H4, W4, 0, "Ge1")); b.bias_grad(ops, Ld1, "Ge1");
+    CK(b.dgrad(ops, Ld1, 1, "Ge1", 0, 0, 64, "tmpH4", nullptr, 0, 0)); b.upadj(ops, "tmpH4", H4, W4, "gt3", 0);
+    // TransformerBlock backward: t3 = a3 + ff2(relu(ff1(attn(q,k,v(a3)))))
+    CK(b.wgrad(ops, Lff2, 1, b.src("f1", 64, H8, W8), 64, H8, W8, 0, "gt3")); b.bias_grad(ops, Lff2, "gt3");
+    CK(b.dgrad(ops, Lff2, 1, "gt3", 0, 0, 64, "gf1", "f1", MASK_RELU, 0));
+    CK(b.wgrad(ops, Lff1, 1, b.src("ao", 64, H8, W8), 64, H8, W8, 0, "gf1")); b.bias_grad(ops, Lff1, "gf1");
+    CK(b.dgrad(ops, Lff1, 1, "gf1", 0, 0, 64, "gao", nullptr, 0, 0));
+    if (!b.dry) {
+        const float* qkv = pl.buf("qkv"); const float* ao = pl.buf("ao"); const float* gao = pl.buf("gao");
+        const float* lse = pl.buf("lse"); float* delta = pl.buf("delta"); float* gqkv = pl.buf("gqkv");
+        const int N = pl.N, T = H8 * W8;
+        ops.push_back([=](hipStream_t st) { return ssie_launch_attn_bwd(qkv, 192, ao, gao, 64, lse, delta, gqkv, N, T, st); });
+    }
+    CK(b.wgrad(ops, Lq, 1, b.src("a3", 64, H8, W8), 64, H8, W8, 0, "gqkv", 0)); b.bias_grad(ops, Lq, "gqkv", 0);
+    CK(b.wgrad(ops, Lk, 1, b.src("a3", 64, H8, W8), 64, H8, W8, 0, "gqkv", 64)); b.bias_grad(ops, Lk, "gqkv", 64);
+    CK(b.wgrad(ops, Lv, 1, b.src("a3", 64, H8, W8), 64, H8, W8, 0, "gqkv", 128)); b.bias_grad(ops, Lv, "gqkv", 128);
+    // g(a3) = [gt3 + dgrad_q + dgrad_k + dgrad_v] * relu'(a3)
+    b.mask_axpy(ops, "gt3", "a3", MASK_RELU, "gt3", 64, 0);
+    CK(b.dgrad(ops, Lq, 1, "gqkv", 0, 0, 64, "gt3", "a3", MASK_RELU, 1));
+    CK(b.dgrad(ops, Lk, 1, "gqkv", 64, 0, 64, "gt3", "a3", MASK_RELU, 1));
+    CK(b.dgrad(ops, Lv, 1, "gqkv", 128, 0, 64, "gt3", "a3", MASK_RELU, 1));
+    CK(b.wgrad(ops, Lc3, 2, b.src("a2", 64, H4, W4), 64, H4, W4, 0, "gt3")); b.bias_grad(ops, Lc3, "gt3");
+    b.mask_axpy(ops, "gd1", "a2", MASK_RELU, "gd1", 64, 0);
+    CK(b.dgrad(ops, Lc3, 2, "gt3", 0, 0, 64, "gd1", "a2", MASK_RELU, 1));
+    CK(b.wgrad(ops, Lc2, 2, b.src("a1", 64, H2, W2), 64, H2, W2, 0, "gd1")); b.bias_grad(ops, Lc2, "gd1");
+    b.mask_axpy(ops, "gd2", "a1", MASK_RELU, "gd2", 64, 0);
+    CK(b.dgrad(ops, Lc2, 2, "gd1", 0, 0, 64, "gd2", "a1", MASK_RELU, 1));
+    CK(b.wgrad(ops, Lc1, 2, b.src("a0", 64, H, W), 64, H, W, 0, "gd2")); b.bias_grad(ops, Lc1, "gd2");
+    CK(b.dgrad(ops, Lc1, 2, "gd2", 0, 0, 64, "gd3", nullptr, 0, 1));
+    CK(b.wgrad(ops, Lc0, 1, b.src("RL_1", pl.CRL, H, W), pl.B + 1, H, W, 0, "gd3")); b.bias_grad(ops, Lc0, "gd3");
+    CK(b.dgrad(ops, Lc0, 1, "gd3", 0, 0, pl.B + 1, "gRL", nullptr, 0, 1));
+    return 0;
+}
+
+int build_all(Plan& pl, bool dry)
+{
+    Builder b(pl, dry);
+    pl.fwd.clear(); pl.pass2.clear(); pl.lossbwd.clear();
+    CK(build_decomposition_fwd(b, pl.fwd, "x", 1));
+    CK(build_illum_fwd(b, pl.fwd));
+    CK(build_decomposition_fwd(b, pl.pass2, "S", 2));
+    std::vector<Fn>& ops = pl.lossbwd;
+    if (!dry) {
+        const int N = pl.N, H = pl.H, W = pl.W, B = pl.B;
+        LossParams lp; memset(&lp, 0, sizeof(lp));
+        lp.x = pl.buf("x"); lp.x_cs = pl.CX; lp.RL = pl.buf("RL_1"); lp.rl_cs = pl.CRL; lp.D = pl.buf("D"); lp.d_cs = 4;
+        lp.S = pl.buf("S"); lp.s_cs = pl.CX; lp.E = pl.buf("RL_2"); lp.e_cs = pl.CRL;
+        lp.gRL = pl.buf("gRL"); lp.gD = pl.buf("gD"); lp.gS = pl.buf("gS"); lp.G8b = pl.buf("G8");
+        lp.N = N; lp.H = H; lp.W = W; lp.B = B;
+        lp.c_rec = pl.coefs[0]; lp.c_rf = pl.coefs[1]; lp.c_il = pl.coefs[2]; lp.c_id = pl.coefs[3]; lp.c_sp = pl.coefs[5];
+        lp.a1 = pl.coefs[6]; lp.a2 = pl.coefs[7];
+        const double n = N, c = B, h = H, w = W;
+        lp.inv_n0 = (float)(1.0 / (n * c * h * w)); lp.inv_nIx = (float)(1.0 / (n * h * (w - 1))); lp.inv_nIy = (float)(1.0 / (n * (h - 1) * w));
+        lp.inv_nRx = (float)(1.0 / (n * c * h * (w - 1))); lp.inv_nRy = (float)(1.0 / (n * c * (h - 1) * w));
+        lp.inv_nsp = (float)(1.0 / (n * (c - 1) * h * w));
+        lp.partials = pl.ws + pl.lpart_off;
+        const int nblk = pl.loss_blocks;
+        ops.push_back([lp, nblk](hipStream_t st) { return ssie_launch_loss_direct(lp, nblk, st); });
+        FftParams fp; memset(&fp, 0, sizeof(fp));
+        fp.x = lp.x; fp.x_cs = lp.x_cs; fp.S = lp.S; fp.s_cs = lp.s_cs; fp.gS = lp.gS; fp.mask = (const uint8_t*)(pl.ws + pl.mask_off);
+        fp.N = N; fp.B = B; fp.H = H; fp.W = W; fp.logH = (int)lround(log2((double)H)); fp.logW = (int)lround(log2((double)W));
+        fp.scale_g = (float)(pl.coefs[4] / (n * c * h * w)); fp.inv_n0 = lp.inv_n0; fp.partials = pl.ws + pl.fpart_off;
+        ops.push_back([fp](hipStream_t st) { return ssie_launch_fft_loss(fp, st); });
+        const float* lpart = pl.ws + pl.lpart_off; const float* fpart = pl.ws + pl.fpart_off; float* scal = pl.ws + pl.scal_off;
+        const int nf = pl.fft_blocks;
+        float cf[6] = {pl.coefs[0], pl.coefs[1], pl.coefs[2], pl.coefs[3], pl.coefs[4], pl.coefs[5]};
+        std::vector<float> cfv(cf, cf + 6);
+        ops.push_back([=](hipStream_t st) { return ssie_launch_loss_finalize(lpart, nblk, fpart, nf, cfv.data(), scal, st); });
+    }
+    CK(build_decomposition_bwd(b, ops, "S", 2, true));
+    if (!dry) {
+        const float* gS = pl.buf("gS"); const float* RL = pl.buf("RL_1"); float* gRL = pl.buf("gRL");
+        const float* D = pl.buf("D"); float* gD = pl.buf("gD");
+        const int cx = pl.CX, rl = pl.CRL, B = pl.B; const long npix = (long)pl.N * pl.H * pl.W;
+        ops.push_back([=](hipStream_t st) { return ssie_launch_product_node(gS, cx, RL, gRL, rl, D, gD, 4, npix, B, st); });
+    }
+    CK(build_illum_bwd(b, ops));
+    b.mask_axpy(ops, "gRL", "RL_1", MASK_SIGMOID, "G8", pl.B + 1, 0);
+    CK(build_decomposition_bwd(b, ops, "x", 1, false));
+    pl.pack_floats_total = pl.pack_cursor;
+    return 0;
+}
+
+int run_ops(std::vector<Fn>& ops, hipStream_t st)
+{
+    for (auto& f : ops) { int rc = f(st); if (rc) return SSIE_E_LAUNCH; }
+    return 0;
+}
+
+} // namespace
+
+// -------------------------------------------------------------------------------------------------
+// C-ABI
+// -------------------------------------------------------------------------------------------------
+extern "C" void* ssie_plan_create(int N, int bands, int H, int W, const float* coefs8)
+{
+    if (N < 1 || bands < 2 || H < 8 || W < 8 || (H & 1) || (W & 1)) return nullptr;   // model.py:59 needs even H, W
+    Plan* pl = new Plan();
+    pl->N = N; pl->B = bands; pl->H = H; pl->W = W;
+    pl->CX = ssie_round_up(bands, 4); pl->CRL = ssie_round_up(bands + 1, 4);
+    pl->H2 = (H + 1) / 2; pl->W2 = (W + 1) / 2; pl->H4 = (pl->H2 + 1) / 2; pl->W4 = (pl->W2 + 1) / 2;
+    pl->H8 = (pl->H4 + 1) / 2; pl->W8 = (pl->W4 + 1) / 2;
+    for (int i = 0; i < 8; ++i) pl->coefs[i] = coefs8 ? coefs8[i] : 0.f;
+    build_params(*pl);
+    build_buffers(*pl);
+    // aliases of tmpH with the lower-resolution geometries
+    BufInfo t = pl->bufs["tmpH"];
+    BufInfo t2 = t; t2.H = pl->H2; t2.W = pl->W2; pl->bufs["tmpH2"] = t2;
+    BufInfo t4 = t; t4.H = pl->H4; t4.W = pl->W4; pl->bufs["tmpH4"] = t4;
+    if (build_all(*pl, true)) { delete pl; return nullptr; }
+    pl->ws_floats = align_up(pl->pack_off + pl->pack_floats_total + 64, 64);
+    return pl;
+}
+
+extern "C" void ssie_plan_destroy(void* h) { delete (Plan*)h; }
+extern "C" size_t ssie_plan_workspace_bytes(void* h) { return h ? ((Plan*)h)->ws_floats * 4 : 0; }
+extern "C" size_t ssie_plan_param_floats(void* h) { return h ? ((Plan*)h)->nparam_floats : 0; }
+extern "C" int ssie_plan_num_params(void* h) { return h ? (int)((Plan*)h)->params.size() : 0; }
+
+extern "C" int ssie_plan_param_info(void* h, int idx, char* name, int name_cap, size_t* off, int* ndim, int* shape4)
+{
+    Plan* pl = (Plan*)h;
+    if (!pl || idx < 0 || idx >= (int)pl->params.size()) return SSIE_E_ARG;
+    const ParamInfo& p = pl->params[idx];
+    if (name) { strncpy(name, p.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (off) *off = p.off; if (ndim) *ndim = p.ndim;
+    if (shape4) for (int i = 0; i < 4; ++i) shape4[i] = p.shape[i];
+    return 0;
+}
+
+extern "C" int ssie_plan_buffer(void* h, const char* name, size_t* off_floats, int* dims5)
+{
+    Plan* pl = (Plan*)h;
+    if (!pl || !name) return SSIE_E_ARG;
+    if (!strcmp(name, "scalars")) { *off_floats = pl->scal_off; dims5[0] = 1; dims5[1] = 1; dims5[2] = 1; dims5[3] = 7; dims5[4] = 16; return 0; }
+    auto it = pl->bufs.find(name);
+    if (it == pl->bufs.end()) return SSIE_E_ARG;
+    *off_floats = it->second.off;
+    dims5[0] = it->second.N; dims5[1] = it->second.H; dims5[2] = it->second.W; dims5[3] = it->second.C; dims5[4] = it->second.cs;
+    return 0;
+}
+
+extern "C" int ssie_plan_set_coefs(void* h, const float* coefs8)
+{
+    Plan* pl = (Plan*)h;
+    if (!pl || !coefs8) return SSIE_E_ARG;
+    for (int i = 0; i < 8; ++i) pl->coefs[i] = coefs8[i];
+    if (pl->bound) return build_all(*pl, false);
+    return 0;
+}
+
+extern "C" int ssie_plan_bind(void* h, void* workspace, size_t ws_bytes, float* params, float* grads, void* stream)
+{
+    Plan* pl = (Plan*)h;
+    if (!pl || !workspace || !params) return SSIE_E_ARG;
+    if (ws_bytes < pl->ws_floats * 4) return SSIE_E_WORKSPACE;
+    if (((uintptr_t)workspace) % 256) return SSIE_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    pl->ws = (float*)workspace; pl->P = params; pl->G = grads;
+    if (hipMemsetAsync(workspace, 0, pl->ws_floats * 4, st) != hipSuccess) return SSIE_E_LAUNCH;
+    int rc = build_all(*pl, false);
+    if (rc) return rc;
+    if (pl->packs.size() > 256) return SSIE_E_WORKSPACE;
+    if (hipMemcpyAsync(pl->ws + pl->packdesc_off, pl->packs.data(), pl->packs.size() * sizeof(PackDesc), hipMemcpyHostToDevice, st) != hipSuccess) return SSIE_E_LAUNCH;
+    if (ssie_fft_supported(pl->H, pl->W)) {
+        std::vector<uint8_t> m((size_t)pl->H * pl->W);
+        ssie_fourier_mask_host(pl->H, pl->W, 0.1f, m.data());
+        if (hipMemcpyAsync(pl->ws + pl->mask_off, m.data(), m.size(), hipMemcpyHostToDevice, st) != hipSuccess) return SSIE_E_LAUNCH;
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) return SSIE_E_LAUNCH;     // host staging buffers go out of scope
+    pl->bound = true;
+    return 0;
+}
+
+static int pack_all(Plan* pl, hipStream_t st)
+{
+    return ssie_launch_pack_batched((const PackDesc*)(pl->ws + pl->packdesc_off), (int)pl->packs.size(), st) ? SSIE_E_LAUNCH : 0;
+}
+
+static int ingest(Plan* pl, const float* x, const long* strides4, hipStream_t st)
+{
+    return ssie_launch_ingest(x, strides4[0], strides4[1], strides4[2], strides4[3], pl->buf("x"), pl->N, pl->B, pl->H, pl->W, pl->CX, st)
+               ? SSIE_E_LAUNCH : 0;
+}
+
+extern "C" int ssie_plan_enhance_fwd(void* h, const float* x, const long* strides4, void* stream)
+{
+    Plan* pl = (Plan*)h;
+    if (!pl || !pl->bound || !x || !strides4) return SSIE_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    CK(pack_all(pl, st));
+    CK(ingest(pl, x, strides4, st));
+    return run_ops(pl->fwd, st);
+}
+
+extern "C" int ssie_plan_loss_fwd_bwd(void* h, const float* x, const long* strides4, int with_backward, void* stream)
+{
+    Plan* pl = (Plan*)h;
+    if (!pl || !pl->bound || !x || !strides4) return SSIE_E_ARG;
+    if (!ssie_fft_supported(pl->H, pl->W)) return SSIE_E_SHAPE;
+    if (with_backward && !pl->G) return SSIE_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    CK(pack_all(pl, st));
+    CK(ingest(pl, x, strides4, st));
+    CK(run_ops(pl->fwd, st));
+    CK(run_ops(pl->pass2, st));
+    if (with_backward) {
+        if (hipMemsetAsync(pl->G, 0, pl->nparam_floats * 4, st) != hipSuccess) return SSIE_E_LAUNCH;
+        return run_ops(pl->lossbwd, st);
+    }
+    // loss only: the first three ops of lossbwd are loss_direct, fft_loss, finalize (they also write cotangents)
+    for (int i = 0; i < 3; ++i) { int rc = pl->lossbwd[i](st); if (rc) return SSIE_E_LAUNCH; }
+    return 0;
+}
+
+extern "C" int ssie_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n,
+                              float grad_scale, float lr, int step, float beta1, float beta2, float eps, void* stream)
+{
+    if (!params || !grads || !exp_avg || !exp_avg_sq || step < 1) return SSIE_E_ARG;
+    return ssie_launch_adam(params, grads, exp_avg, exp_avg_sq, (long)n, grad_scale, lr, step, beta1, beta2, eps, (hipStream_t)stream)
+               ? SSIE_E_LAUNCH : 0;
+}

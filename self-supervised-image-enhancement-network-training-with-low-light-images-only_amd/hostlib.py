@@ -163,3 +163,122 @@ def conv_transpose2d_wgrad(x, g, cin, cout):
                                            ptr(ws), C.c_size_t(ws.numel() * 4), stream_ptr())
     check(rc, "ssie_conv_transpose2d_wgrad")
     return dw, db
+
+
+# ---- plan executor (whole hot path) ---------------------------------------------------------------
+COEF_ORDER = ("c_rec", "c_rf", "c_il", "c_id", "c_f", "c_sp", "alpha_low", "alpha_delta")
+LOSS_KEYS = ("total_loss", "L_reconstruction", "L_R_fidelity", "L_I_smooth_low",
+             "L_I_smooth_delta", "L_fourier", "L_spectral_cons")
+
+
+def _proto():
+    L = lib()
+    L.ssie_plan_create.restype = C.c_void_p
+    L.ssie_plan_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.ssie_plan_destroy.argtypes = [C.c_void_p]
+    L.ssie_plan_workspace_bytes.restype = C.c_size_t
+    L.ssie_plan_workspace_bytes.argtypes = [C.c_void_p]
+    L.ssie_plan_param_floats.restype = C.c_size_t
+    L.ssie_plan_param_floats.argtypes = [C.c_void_p]
+    L.ssie_plan_num_params.argtypes = [C.c_void_p]
+    L.ssie_plan_param_info.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_size_t),
+                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.ssie_plan_buffer.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+    L.ssie_plan_set_coefs.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.ssie_plan_bind.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ssie_plan_enhance_fwd.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_long), C.c_void_p]
+    L.ssie_plan_loss_fwd_bwd.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_long), C.c_int, C.c_void_p]
+    L.ssie_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float,
+                                 C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]
+    L.ssie_fourier_mask.argtypes = [C.c_int, C.c_int, C.c_float, C.c_void_p]
+    return L
+
+
+def param_table(bands: int):
+    """[(state-dict key, float offset in the flat buffer, shape)], total floats — from the C side (single source of truth)."""
+    L = _proto()
+    coefs = (C.c_float * 8)(*([0.0] * 8))
+    h = L.ssie_plan_create(1, bands, 16, 16, coefs)
+    if not h:
+        raise SsieError("ssie_plan_create failed")
+    try:
+        out = []
+        name = C.create_string_buffer(128)
+        for i in range(L.ssie_plan_num_params(h)):
+            off = C.c_size_t(); nd = C.c_int(); shp = (C.c_int * 4)()
+            check(L.ssie_plan_param_info(h, i, name, 128, C.byref(off), C.byref(nd), shp), "ssie_plan_param_info")
+            out.append((name.value.decode(), off.value, tuple(shp[:nd.value])))
+        return out, L.ssie_plan_param_floats(h)
+    finally:
+        L.ssie_plan_destroy(h)
+
+
+def fourier_mask(h: int, w: int, cutoff: float = 0.1):
+    import numpy as np
+    m = np.zeros((h, w), dtype=np.uint8)
+    check(_proto().ssie_fourier_mask(h, w, cutoff, m.ctypes.data_as(C.c_void_p)), "ssie_fourier_mask")
+    return m
+
+
+class Plan:
+    """One (N, bands, H, W) instance of the hot path bound to flat parameter / gradient buffers."""
+
+    def __init__(self, n, bands, h, w, coefs: dict, flat_params: torch.Tensor, flat_grads: torch.Tensor | None):
+        self.L = _proto()
+        self.shape = (n, bands, h, w)
+        cf = (C.c_float * 8)(*[float(coefs[k]) for k in COEF_ORDER])
+        self.h = self.L.ssie_plan_create(n, bands, h, w, cf)
+        if not self.h:
+            raise SsieError(f"unsupported plan shape N={n} B={bands} H={h} W={w} (H, W must be even and >= 8)")
+        dev = flat_params.device
+        nbytes = self.L.ssie_plan_workspace_bytes(self.h)
+        self.ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+        self.flat_params, self.flat_grads = flat_params, flat_grads
+        check(self.L.ssie_plan_bind(self.h, self.ws.data_ptr(), nbytes, flat_params.data_ptr(),
+                                    0 if flat_grads is None else flat_grads.data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream), "ssie_plan_bind")
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.L.ssie_plan_destroy(self.h); self.h = None
+        except Exception:
+            pass
+
+    def set_coefs(self, coefs: dict):
+        cf = (C.c_float * 8)(*[float(coefs[k]) for k in COEF_ORDER])
+        check(self.L.ssie_plan_set_coefs(self.h, cf), "ssie_plan_set_coefs")
+
+    def buffer(self, name: str) -> torch.Tensor:
+        """NHWC view (N,H,W,C) of a named workspace buffer (padding channels dropped)."""
+        off = C.c_size_t(); d = (C.c_int * 5)()
+        check(self.L.ssie_plan_buffer(self.h, name.encode(), C.byref(off), d), f"ssie_plan_buffer({name})")
+        n, h, w, c, cs = d[0], d[1], d[2], d[3], d[4]
+        return torch.as_strided(self.ws, (n, h, w, c), (h * w * cs, w * cs, cs, 1), off.value)
+
+    def nchw(self, name: str, c0: int = 0, c1: int | None = None) -> torch.Tensor:
+        """logical (N,C,H,W) view of channels [c0, c1) — the reference's tensor convention."""
+        b = self.buffer(name)
+        return b[..., c0:c1].permute(0, 3, 1, 2)
+
+    def _strides(self, x):
+        n, b, h, w = self.shape
+        if tuple(x.shape) != (n, b, h, w) or x.dtype != torch.float32 or not x.is_cuda:
+            raise SsieError(f"expected float32 cuda tensor of shape {(n, b, h, w)}, got {tuple(x.shape)} {x.dtype} {x.device}")
+        return (C.c_long * 4)(*x.stride())
+
+    def enhance_fwd(self, x):
+        check(self.L.ssie_plan_enhance_fwd(self.h, x.data_ptr(), self._strides(x), torch.cuda.current_stream().cuda_stream),
+              "ssie_plan_enhance_fwd")
+
+    def loss_fwd_bwd(self, x, backward=True):
+        check(self.L.ssie_plan_loss_fwd_bwd(self.h, x.data_ptr(), self._strides(x), int(backward),
+                                            torch.cuda.current_stream().cuda_stream), "ssie_plan_loss_fwd_bwd")
+
+    def loss_scalars(self) -> torch.Tensor:
+        return self.buffer("scalars").reshape(7)
+
+
+def adam_step(params, grads, m, v, step, lr, grad_scale=1.0, b1=0.9, b2=0.999, eps=1e-8):
+    check(_proto().ssie_adam_step(params.data_ptr(), grads.data_ptr(), m.data_ptr(), v.data_ptr(), params.numel(),
+                                  grad_scale, lr, step, b1, b2, eps, torch.cuda.current_stream().cuda_stream), "ssie_adam_step")
