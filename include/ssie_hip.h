@@ -87,6 +87,12 @@ int ssie_conv_transpose2d_wgrad(const ssie_src_t* x, int N, const float* g, int 
                                 float* dw, float* db, int accumulate,
                                 void* ws, size_t ws_bytes, void* stream);
 
+/* 4-head x 16-dim softmax self-attention over T tokens (model.py:107-114) and its backward.
+ * qkv: (N*T, 192) rows = tokens, q|k|v at channel 0|64|128; out/gout: (N*T, 64); lse, delta_ws: (N,4,T) */
+int ssie_attention_fwd(const float* qkv, float* out, float* lse, int N, int T, void* stream);
+int ssie_attention_bwd(const float* qkv, const float* out, const float* gout, const float* lse,
+                       float* delta_ws, float* gqkv, int N, int T, void* stream);
+
 /* ---- plan executor: the whole hot path as a static launch schedule -----------------------------
  * coefs8 = {c_loss_reconstruction, c_loss_r_fidelity, c_loss_i_smooth_low, c_loss_i_smooth_delta,
  *           c_loss_fourier, c_loss_spectral_cons, alpha_i_smooth_low, alpha_i_smooth_delta}

@@ -87,21 +87,30 @@ def param_shapes(bands: int, channel: int = CHANNEL) -> "OrderedDict[str, tuple]
     return spec
 
 
+def _hash_uniform(n: int, stream: int) -> np.ndarray:
+    """n pseudo-random float64 in [0,1): splitmix64-style integer hash of (index, stream) — pure integer
+    arithmetic, so it is bit-identical on every machine (no libm involved)."""
+    with np.errstate(over="ignore"):
+        h = (np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+             + np.uint64(stream + 1) * np.uint64(0xBF58476D1CE4E5B9))
+        h ^= h >> np.uint64(30); h *= np.uint64(0xBF58476D1CE4E5B9)
+        h ^= h >> np.uint64(27); h *= np.uint64(0x94D049BB133111EB)
+        h ^= h >> np.uint64(31)
+    return (h >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+
+
 def closed_form_params(bands: int, channel: int = CHANNEL, dtype=torch.float32, gain: float = 1.0):
-    """Deterministic, RNG-free parameter fill: p.flat[i] = a_t * sin(0.37 i + t),
-    a_t = gain / sqrt(fan_in).  Regenerated bit-identically wherever numpy runs."""
+    """Deterministic, RNG-library-free parameter fill (full-rank, unlike a sinusoid):
+    p.flat[i] = a_t * (2 u(i, t) - 1), u = integer hash, a_t = gain / sqrt(fan_in)  (PyTorch's default bound).
+    Regenerated bit-identically wherever numpy runs, so fixtures carry reference OUTPUTS only."""
     out = OrderedDict()
     for t, (name, shape) in enumerate(param_shapes(bands, channel).items()):
         n = int(np.prod(shape))
-        if name.endswith(".weight"):
-            fan_in = int(np.prod(shape[1:]))
-            if "deconv.0.weight" in name and name.startswith("decomposition_net."):
-                fan_in = shape[0] * shape[2] * shape[3]
-        else:
-            fan_in = 16
+        wname = name[:-5] + ".weight" if name.endswith(".bias") else name
+        wshape = param_shapes(bands, channel)[wname]
+        fan_in = int(np.prod(wshape[1:]))
         a = gain / math.sqrt(fan_in)
-        idx = np.arange(n, dtype=np.float64)
-        vals = a * np.sin(0.37 * idx + float(t))
+        vals = a * (2.0 * _hash_uniform(n, t) - 1.0)
         out[name] = torch.from_numpy(vals.reshape(shape)).to(dtype)
     return out
 
@@ -114,8 +123,7 @@ def synthetic_patches(n: int, bands: int, h: int, w: int, seed: int = 41, dtype=
     illum = 0.55 + 0.35 * np.sin(0.11 * hh + 0.3 * nn_ + 0.01 * seed) * np.cos(0.07 * ww - 0.2 * nn_)
     refl = 0.5 + 0.3 * np.sin(0.45 * cc + 0.05 * hh - 0.04 * ww + 0.7 * nn_) \
                + 0.15 * np.cos(0.9 * cc - 0.13 * ww + 0.21 * hh)
-    lin = ((nn_ * bands + cc) * h + hh) * w + ww
-    noise = np.modf(np.abs(np.sin(lin * 12.9898 + seed * 78.233)) * 43758.5453)[0] - 0.5
+    noise = _hash_uniform(n * bands * h * w, 1000 + seed).reshape(n, bands, h, w) - 0.5
     x = np.clip(illum * refl + 0.01 * noise, 0.0, 1.0) * 0.3
     t = torch.from_numpy(x).to(dtype)
     return t.contiguous(memory_format=torch.channels_last)

@@ -176,3 +176,17 @@ int ssie_launch_attn_bwd(const float* qkv, int qs, const float* o, const float* 
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, qkv, qs, go, os, lse, delta, gqkv, T, 0.25f);
     return hipGetLastError() == hipSuccess ? 0 : 62;
 }
+
+// ---- granular C-ABI (parity tests) ----
+extern "C" int ssie_attention_fwd(const float* qkv, float* out, float* lse, int N, int T, void* stream)
+{
+    if (!qkv || !out || !lse || N < 1 || T < 1) return 1;
+    return ssie_launch_attn_fwd(qkv, 192, out, 64, lse, N, T, (hipStream_t)stream) ? 4 : 0;
+}
+
+extern "C" int ssie_attention_bwd(const float* qkv, const float* out, const float* gout, const float* lse,
+                                  float* delta_ws, float* gqkv, int N, int T, void* stream)
+{
+    if (!qkv || !out || !gout || !lse || !delta_ws || !gqkv || N < 1 || T < 1) return 1;
+    return ssie_launch_attn_bwd(qkv, 192, out, gout, 64, lse, delta_ws, gqkv, N, T, (hipStream_t)stream) ? 4 : 0;
+}

@@ -282,3 +282,19 @@ class Plan:
 def adam_step(params, grads, m, v, step, lr, grad_scale=1.0, b1=0.9, b2=0.999, eps=1e-8):
     check(_proto().ssie_adam_step(params.data_ptr(), grads.data_ptr(), m.data_ptr(), v.data_ptr(), params.numel(),
                                   grad_scale, lr, step, b1, b2, eps, torch.cuda.current_stream().cuda_stream), "ssie_adam_step")
+
+
+def attention_fwd(qkv: torch.Tensor):
+    """qkv: (N, T, 192) -> out (N, T, 64), lse (N, 4, T)"""
+    n, t, _ = qkv.shape
+    out = torch.empty(n, t, 64, device=qkv.device); lse = torch.empty(n, 4, t, device=qkv.device)
+    check(lib().ssie_attention_fwd(ptr(qkv), ptr(out), ptr(lse), n, t, stream_ptr()), "ssie_attention_fwd")
+    return out, lse
+
+
+def attention_bwd(qkv, out, gout, lse):
+    n, t, _ = qkv.shape
+    gqkv = torch.empty_like(qkv); delta = torch.empty_like(lse)
+    check(lib().ssie_attention_bwd(ptr(qkv), ptr(out), ptr(gout), ptr(lse), ptr(delta), ptr(gqkv), n, t, stream_ptr()),
+          "ssie_attention_bwd")
+    return gqkv

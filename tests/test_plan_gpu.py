@@ -2,7 +2,8 @@
 
 Stage-by-stage: every forward activation, the seven loss scalars, the loss cotangents, a set of
 intermediate gradients and all 46 parameter gradients, then Adam.  Tolerances:
-outputs abs <= 1e-5, loss scalars rel <= 1e-5, gradients rel-L2 <= 1e-3 per tensor
+outputs abs <= 1e-5, loss scalars rel <= 1e-5 vs the fp32 reference fixtures (5e-5 vs the fp64 oracle: the reference's own
+fp32 rounding of these ~1e-4 means is ~1e-5), gradients rel-L2 <= 1e-3 per tensor
 (`k_linear.bias` excluded: analytically zero), enhanced-cube PSNR vs oracle > 100 dB.
 The golden fixtures (reference outputs) are checked too, so the chain reference -> oracle -> HIP is closed.
 """
@@ -88,8 +89,8 @@ def test_stagewise_parity(pkg, case):
     ref_l = np.array([vals[k] for k in O.LOSS_KEYS])
     for k, g, r in zip(O.LOSS_KEYS, got_l, ref_l):
         e = abs(g - r) / max(abs(r), 1e-30)
-        report.append(f"{k:34s} rel {e:.3e} (tol 1e-05)  hip={g:.8e} oracle={r:.8e}")
-        if e > 1e-5:
+        report.append(f"{k:34s} rel {e:.3e} (tol 5e-05 vs fp64 oracle)  hip={g:.8e} oracle={r:.8e}")
+        if e > 5e-5:
             bad.append(report[-1])
 
     # intermediate gradients (state at the END of the step = pass-1 backward)
@@ -130,7 +131,7 @@ def test_golden_reference_outputs(pkg, golden_dir, case):
         else:
             assert np.abs(t[:, ::5, ::7, ::9].numpy() - g[key + "_sub"]).max() <= 1e-5, key
     ref = g["losses"]; mine = plan.loss_scalars().cpu().double().numpy()
-    assert np.all(np.abs(mine - ref) <= 2e-5 * np.abs(ref) + 1e-9), (mine, ref)
+    assert np.all(np.abs(mine - ref) <= 1e-5 * np.abs(ref) + 1e-9), (mine, ref)
     names = [str(s) for s in g["grad_names"]]
     for (name, off, shape), ref_norm in zip(table, g["grad_norms"]):
         if name.endswith("k_linear.bias"):
