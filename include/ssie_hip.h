@@ -128,6 +128,13 @@ int ssie_plan_enhance_fwd(void* plan, const float* x, const long* strides4, void
  * The Fourier term needs power-of-two H, W with H*(W+1)*8 bytes <= 160 KiB LDS (SSIE_E_SHAPE otherwise). */
 int ssie_plan_loss_fwd_bwd(void* plan, const float* x, const long* strides4, int with_backward, void* stream);
 
+/* one compute_loss+backward with a HIP event after every launch: device milliseconds, algorithmic FLOPs and
+ * launch counts per kernel class (synchronises; used by bench.py's roofline leg).  Arrays have 10 entries:
+ * {conv_fprop<64>, conv_fprop<32>, conv_wgrad, wgrad_reduce, colsum, pack, loss, fft_loss, attention, elementwise} */
+#define SSIE_NKINDS 10
+int ssie_plan_profile_step(void* plan, const float* x, const long* strides4, void* stream,
+                           double* ms, double* flops, int* counts);
+
 /* torch.optim.Adam.step with default hyper-parameters (model.py:213, :316) over flat buffers;
  * grads are multiplied by grad_scale first (1/world_size after an all-reduce-sum) */
 int ssie_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n,

@@ -63,8 +63,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     }
 }
 
-// dQ: one thread per query row.  p_ij = exp(s_ij - lse_i), dS = p (dP - delta), dQ_i = scale * sum_j dS_ij K_j
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ qkv, int qs, const float* __restrict__ o,
+// dQ: one thread per query row.  p_ij = exp(s_ij - lse_i), dS = p (dP - delta), dQ_i = scale * sum_j dS_ij K_j.
+// delta_i = sum_j p_ij dP_ij / sum_j p_ij is accumulated from the SAME p and dP that form dS (first sweep), so
+// sum_j dS_ij cancels to rounding like torch's softmax backward does; the cheaper dO.O form leaves an error
+// proportional to mean(K) that swamps the (often tiny) query/key gradients of this block.
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ qkv, int qs,
                                                           const float* __restrict__ go, int os, const float* __restrict__ lse,
                                                           float* __restrict__ gqkv, float* __restrict__ delta, int T, float scale)
 {
@@ -74,35 +77,45 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
     const int qi = blockIdx.x * 256 + tid;
     const float* base = qkv + (size_t)n * T * qs;
     float q[AT_D], dO[AT_D], dq[AT_D];
-    float dl = 0.f, ls = 0.f;
+    float ls = 0.f;
 #pragma unroll
     for (int d = 0; d < AT_D; ++d) {
         q[d] = qi < T ? base[(size_t)qi * qs + head * AT_D + d] * scale : 0.f;
         dO[d] = qi < T ? go[((size_t)n * T + qi) * os + head * AT_D + d] : 0.f;
-        const float ov = qi < T ? o[((size_t)n * T + qi) * os + head * AT_D + d] : 0.f;
-        dl += dO[d] * ov; dq[d] = 0.f;
+        dq[d] = 0.f;
     }
-    if (qi < T) { ls = lse[((size_t)n * 4 + head) * T + qi]; delta[((size_t)n * 4 + head) * T + qi] = dl; }
-    for (int k0 = 0; k0 < T; k0 += AT_TILE) {
-        __syncthreads();
-        for (int id = tid; id < AT_TILE * 4; id += 256) {
-            const int r = id >> 2, c4 = (id & 3) * 4;
-            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-            if (k0 + r < T) {
-                kv = *(const f32x4*)(base + (size_t)(k0 + r) * qs + 64 + head * AT_D + c4);
-                vv = *(const f32x4*)(base + (size_t)(k0 + r) * qs + 128 + head * AT_D + c4);
+    if (qi < T) ls = lse[((size_t)n * 4 + head) * T + qi];
+    float sp = 0.f, spd = 0.f, dl = 0.f;
+    for (int sweep = 0; sweep < 2; ++sweep) {
+        for (int k0 = 0; k0 < T; k0 += AT_TILE) {
+            __syncthreads();
+            for (int id = tid; id < AT_TILE * 4; id += 256) {
+                const int r = id >> 2, c4 = (id & 3) * 4;
+                f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+                if (k0 + r < T) {
+                    kv = *(const f32x4*)(base + (size_t)(k0 + r) * qs + 64 + head * AT_D + c4);
+                    vv = *(const f32x4*)(base + (size_t)(k0 + r) * qs + 128 + head * AT_D + c4);
+                }
+                *(f32x4*)&Ks[r][c4] = kv; *(f32x4*)&Vs[r][c4] = vv;
             }
-            *(f32x4*)&Ks[r][c4] = kv; *(f32x4*)&Vs[r][c4] = vv;
+            __syncthreads();
+            const int kn = min(AT_TILE, T - k0);
+            for (int j = 0; j < kn; ++j) {
+                float s = 0.f, dp = 0.f;
+#pragma unroll
+                for (int d = 0; d < AT_D; ++d) { s += q[d] * Ks[j][d]; dp += dO[d] * Vs[j][d]; }
+                const float pj = expf(s - ls);
+                if (sweep == 0) { sp += pj; spd += pj * dp; }
+                else {
+                    const float ds = pj * (dp - dl);
+#pragma unroll
+                    for (int d = 0; d < AT_D; ++d) dq[d] += ds * Ks[j][d];
+                }
+            }
         }
-        __syncthreads();
-        const int kn = min(AT_TILE, T - k0);
-        for (int j = 0; j < kn; ++j) {
-            float s = 0.f, dp = 0.f;
-#pragma unroll
-            for (int d = 0; d < AT_D; ++d) { s += q[d] * Ks[j][d]; dp += dO[d] * Vs[j][d]; }
-            const float ds = expf(s - ls) * (dp - dl);
-#pragma unroll
-            for (int d = 0; d < AT_D; ++d) dq[d] += ds * Ks[j][d];
+        if (sweep == 0) {
+            dl = spd / sp;
+            if (qi < T) delta[((size_t)n * 4 + head) * T + qi] = dl;
         }
     }
     if (qi < T)
@@ -172,7 +185,7 @@ int ssie_launch_attn_bwd(const float* qkv, int qs, const float* o, const float* 
                          float* delta, float* gqkv, int N, int T, hipStream_t st)
 {
     dim3 grid((T + 255) / 256, 4, N);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, qkv, qs, o, go, os, lse, gqkv, delta, T, 0.25f);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, qkv, qs, go, os, lse, gqkv, delta, T, 0.25f);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, qkv, qs, go, os, lse, delta, gqkv, T, 0.25f);
     return hipGetLastError() == hipSuccess ? 0 : 62;
 }

@@ -20,7 +20,14 @@
 
 namespace {
 
-typedef std::function<int(hipStream_t)> Fn;
+typedef std::function<int(hipStream_t)> FnT;
+// op kinds for per-kernel-class profiling (bench.py roofline): see ssie_plan_profile_step
+enum { K_FPROP2 = 0, K_FPROP1, K_WGRAD, K_WGRAD_REDUCE, K_COLSUM, K_PACK, K_LOSS, K_FFT, K_ATTN, K_ELEMENTWISE, K_NKINDS };
+struct Fn {
+    FnT fn; int kind; double flops;
+    Fn(FnT f, int k = K_ELEMENTWISE, double fl = 0.0) : fn(std::move(f)), kind(k), flops(fl) {}
+    int operator()(hipStream_t st) const { return fn(st); }
+};
 
 struct ParamInfo { std::string name; size_t off; int shape[4]; int ndim; size_t numel; };
 struct BufInfo { size_t off; int N, H, W, C, cs; };
@@ -164,7 +171,13 @@ struct Builder {
     float* ptr(const char* name) { return dry ? nullptr : pl.buf(name); }
     float* par(size_t off) { return dry ? nullptr : pl.P + off; }
     float* grad(size_t off) { return dry ? nullptr : pl.G + off; }
-    void push(std::vector<Fn>& ops, const ConvParams& p) { if (!dry) ops.push_back([p](hipStream_t st) { return ssie_launch_fprop(p, st); }); }
+    void push(std::vector<Fn>& ops, const ConvParams& p, int k_real)
+    {
+        if (dry) return;
+        // algorithmic FLOPs: real (un-padded) channels and taps only
+        const double fl = 2.0 * p.N * p.Ho * p.Wo * (double)p.Cout * k_real * p.ntaps;
+        ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_fprop(p, st); }, p.Cout_pad % 64 == 0 ? K_FPROP2 : K_FPROP1, fl));
+    }
 
     // forward conv (stride 1/2) over concatenated / up-sampled sources
     int conv(std::vector<Fn>& ops, const LayerP& L, std::vector<SrcDesc> srcs, int Hv, int Wv, int stride,
@@ -184,7 +197,7 @@ struct Builder {
         int rc = ssie_make_conv(p, srcs.data(), (int)srcs.size(), pl.N, Hv, Wv, t, stride, Ho, Wo, wp, L.cout,
                                 pl.buf(out), ob.H, ob.W, ob.cs, out_coff, 1, 0, 0, e);
         if (rc) return rc;
-        push(ops, p);
+        push(ops, p, L.cin);
         return 0;
     }
 
@@ -202,7 +215,7 @@ struct Builder {
             const int Ho = ssie_ceil_div(ob.H - py, 2), Wo = ssie_ceil_div(ob.W - px, 2);
             int rc = ssie_make_conv(p, &in, 1, pl.N, Hin, Win, t, 1, Ho, Wo, wp, Nc, pl.buf(out), ob.H, ob.W, ob.cs, 0, 2, py, px, e);
             if (rc) return rc;
-            push(ops, p);
+            push(ops, p, Kc);
         }
         return 0;
     }
@@ -231,7 +244,7 @@ struct Builder {
             ConvParams p;
             int rc = ssie_make_conv(p, &in, 1, pl.N, gb.H, gb.W, t, 1, xb.H, xb.W, wp, cs, pl.buf(gx), xb.H, xb.W, xb.cs, 0, 1, 0, 0, e);
             if (rc) return rc;
-            push(ops, p);
+            push(ops, p, L.cout);
             return 0;
         }
         return transposed(ops, wbase, L.cout, cs, L.cin * T, T, in, gb.H, gb.W, gx, e);
@@ -253,8 +266,9 @@ struct Builder {
         const long s_co = (long)L.cin * T;
         const float* slabs = pl.ws + pl.slab_off;
         const int cout = L.cout;
-        ops.push_back([p](hipStream_t st) { return ssie_launch_wgrad(p, st); });
-        ops.push_back([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, p.nslices, p.ntaps, p.ci_pad, p.co_pad, creal, cout, dw, s_co, T, 1, 1, st); });
+        const double fl = 2.0 * pl.N * Ho * Wo * (double)cout * creal * T;
+        ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_wgrad(p, st); }, K_WGRAD, fl));
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, p.nslices, p.ntaps, p.ci_pad, p.co_pad, creal, cout, dw, s_co, T, 1, 1, st); }, K_WGRAD_REDUCE));
         return 0;
     }
 
@@ -264,7 +278,7 @@ struct Builder {
         const BufInfo& gb = pl.bi(g);
         const float* gp = pl.buf(g); float* part = pl.ws + pl.partial_off; float* db = pl.G + L.b;
         const long npix = (long)gb.N * gb.H * gb.W; const int cs = gb.cs, C = L.cout;
-        ops.push_back([=](hipStream_t st) { return ssie_launch_colsum(gp, npix, cs, g_coff, C, part, 256, db, 1, st); });
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_colsum(gp, npix, cs, g_coff, C, part, 256, db, 1, st); }, K_COLSUM));
     }
 
     void mask_axpy(std::vector<Fn>& ops, const char* src, const char* y, int mode, const char* dst, int C, int accumulate)
@@ -274,7 +288,7 @@ struct Builder {
         const float* sp = pl.buf(src); const float* yp = y ? pl.buf(y) : nullptr; float* dp = pl.buf(dst);
         const int ycs = y ? pl.bi(y).cs : 0, scs = sb.cs, dcs = db.cs;
         const long npix = (long)sb.N * sb.H * sb.W;
-        ops.push_back([=](hipStream_t st) { return ssie_launch_mask_axpy(sp, scs, yp, ycs, mode, dp, dcs, npix, C, accumulate, st); });
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_mask_axpy(sp, scs, yp, ycs, mode, dp, dcs, npix, C, accumulate, st); }));
     }
 
     void upadj(std::vector<Fn>& ops, const char* src, int Hv, int Wv, const char* dst, int accumulate)
@@ -283,7 +297,7 @@ struct Builder {
         const BufInfo& db = pl.bi(dst);
         const float* sp = pl.buf(src); float* dp = pl.buf(dst);
         const int scs = pl.bi(src).cs, dcs = db.cs, Hs = db.H, Ws = db.W, N = pl.N;
-        ops.push_back([=](hipStream_t st) { return ssie_launch_upsample_adjoint(sp, Hv, Wv, scs, dp, Hs, Ws, dcs, N, 64, accumulate, st); });
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_upsample_adjoint(sp, Hv, Wv, scs, dp, Hs, Ws, dcs, N, 64, accumulate, st); }));
     }
 };
 
@@ -328,7 +342,7 @@ int build_illum_fwd(Builder& b, std::vector<Fn>& ops)
     if (!b.dry) {
         const float* qkv = pl.buf("qkv"); float* ao = pl.buf("ao"); float* lse = pl.buf("lse");
         const int N = pl.N, T = H8 * W8;
-        ops.push_back([=](hipStream_t st) { return ssie_launch_attn_fwd(qkv, 192, ao, 64, lse, N, T, st); });
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_attn_fwd(qkv, 192, ao, 64, lse, N, T, st); }, K_ATTN, 4.0 * N * 4 * (double)T * T * 16));
     }
     CK(b.conv(ops, layer(pl, i + "attn.ff_linear1"), {b.src("ao", 64, H8, W8)}, H8, W8, 1, "f1", ACT_RELU));
     CK(b.conv(ops, layer(pl, i + "attn.ff_linear2"), {b.src("f1", 64, H8, W8)}, H8, W8, 1, "t3", ACT_NONE, "a3"));
@@ -340,7 +354,7 @@ int build_illum_fwd(Builder& b, std::vector<Fn>& ops)
     if (!b.dry) {
         const float* RL = pl.buf("RL_1"); const float* D = pl.buf("D"); float* S = pl.buf("S");
         const int rl = pl.CRL, cx = pl.CX, B = pl.B; const long npix = (long)pl.N * H * W;
-        ops.push_back([=](hipStream_t st) { return ssie_launch_compose(RL, rl, D, 4, S, cx, npix, B, st); });
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_compose(RL, rl, D, 4, S, cx, npix, B, st); }));
     }
     return 0;
 }
@@ -374,8 +388,8 @@ int build_decomposition_bwd(Builder& b, std::vector<Fn>& ops, const char* xin, i
         CK(ssie_make_wgrad(wp, gs, pl.N, H, W, 0, pl.buf(c3.c_str()), cb.cs, 0, 128, H2, W2, 2, t, pl.ws + pl.slab_off, kWgs));
         if (ssie_wgrad_slab_floats(wp) > pl.slab_cap) return SSIE_E_WORKSPACE;
         float* dw = pl.G + Ld.w; const float* slabs = pl.ws + pl.slab_off;
-        ops.push_back([wp](hipStream_t st) { return ssie_launch_wgrad(wp, st); });
-        ops.push_back([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, wp.nslices, wp.ntaps, wp.ci_pad, wp.co_pad, 64, 128, dw, 64L * 9, 9, 1, 1, st); });
+        ops.push_back(Fn([wp](hipStream_t st) { return ssie_launch_wgrad(wp, st); }, K_WGRAD, 2.0 * pl.N * H2 * W2 * 128.0 * 64 * 9));
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, wp.nslices, wp.ntaps, wp.ci_pad, wp.co_pad, 64, 128, dw, 64L * 9, 9, 1, 1, st); }, K_WGRAD_REDUCE));
     }
     b.bias_grad(ops, Ld, "Gdc");
     {
@@ -387,7 +401,7 @@ int build_decomposition_bwd(Builder& b, std::vector<Fn>& ops, const char* xin, i
             Epilogue e = b.bwd_epi(c3.c_str(), MASK_RELU, 0);
             ConvParams cp; const BufInfo& ob = pl.bi("G3");
             CK(ssie_make_conv(cp, &in, 1, pl.N, H, W, t, 2, H2, W2, wpk, 128, pl.buf("G3"), ob.H, ob.W, ob.cs, 0, 1, 0, 0, e));
-            b.push(ops, cp);
+            b.push(ops, cp, 64);
         }
     }
     CK(b.wgrad(ops, L3, 1, b.src(c2.c_str(), 128, H2, W2), 128, H2, W2, 0, "G3")); b.bias_grad(ops, L3, "G3");
@@ -444,7 +458,7 @@ int build_illum_bwd(Builder& b, std::vector<Fn>& ops)
         const float* qkv = pl.buf("qkv"); const float* ao = pl.buf("ao"); const float* gao = pl.buf("gao");
         const float* lse = pl.buf("lse"); float* delta = pl.buf("delta"); float* gqkv = pl.buf("gqkv");
         const int N = pl.N, T = H8 * W8;
-        ops.push_back([=](hipStream_t st) { return ssie_launch_attn_bwd(qkv, 192, ao, gao, 64, lse, delta, gqkv, N, T, st); });
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_attn_bwd(qkv, 192, ao, gao, 64, lse, delta, gqkv, N, T, st); }, K_ATTN, 8.0 * N * 4 * (double)T * T * 16));
     }
     CK(b.wgrad(ops, Lq, 1, b.src("a3", 64, H8, W8), 64, H8, W8, 0, "gqkv", 0)); b.bias_grad(ops, Lq, "gqkv", 0);
     CK(b.wgrad(ops, Lk, 1, b.src("a3", 64, H8, W8), 64, H8, W8, 0, "gqkv", 64)); b.bias_grad(ops, Lk, "gqkv", 64);
@@ -490,24 +504,24 @@ int build_all(Plan& pl, bool dry)
         lp.inv_nsp = (float)(1.0 / (n * (c - 1) * h * w));
         lp.partials = pl.ws + pl.lpart_off;
         const int nblk = pl.loss_blocks;
-        ops.push_back([lp, nblk](hipStream_t st) { return ssie_launch_loss_direct(lp, nblk, st); });
+        ops.push_back(Fn([lp, nblk](hipStream_t st) { return ssie_launch_loss_direct(lp, nblk, st); }, K_LOSS));
         FftParams fp; memset(&fp, 0, sizeof(fp));
         fp.x = lp.x; fp.x_cs = lp.x_cs; fp.S = lp.S; fp.s_cs = lp.s_cs; fp.gS = lp.gS; fp.mask = (const uint8_t*)(pl.ws + pl.mask_off);
         fp.N = N; fp.B = B; fp.H = H; fp.W = W; fp.logH = (int)lround(log2((double)H)); fp.logW = (int)lround(log2((double)W));
         fp.scale_g = (float)(pl.coefs[4] / (n * c * h * w)); fp.inv_n0 = lp.inv_n0; fp.partials = pl.ws + pl.fpart_off;
-        ops.push_back([fp](hipStream_t st) { return ssie_launch_fft_loss(fp, st); });
+        ops.push_back(Fn([fp](hipStream_t st) { return ssie_launch_fft_loss(fp, st); }, K_FFT));
         const float* lpart = pl.ws + pl.lpart_off; const float* fpart = pl.ws + pl.fpart_off; float* scal = pl.ws + pl.scal_off;
         const int nf = pl.fft_blocks;
         float cf[6] = {pl.coefs[0], pl.coefs[1], pl.coefs[2], pl.coefs[3], pl.coefs[4], pl.coefs[5]};
         std::vector<float> cfv(cf, cf + 6);
-        ops.push_back([=](hipStream_t st) { return ssie_launch_loss_finalize(lpart, nblk, fpart, nf, cfv.data(), scal, st); });
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_loss_finalize(lpart, nblk, fpart, nf, cfv.data(), scal, st); }, K_LOSS));
     }
     CK(build_decomposition_bwd(b, ops, "S", 2, true));
     if (!dry) {
         const float* gS = pl.buf("gS"); const float* RL = pl.buf("RL_1"); float* gRL = pl.buf("gRL");
         const float* D = pl.buf("D"); float* gD = pl.buf("gD");
         const int cx = pl.CX, rl = pl.CRL, B = pl.B; const long npix = (long)pl.N * pl.H * pl.W;
-        ops.push_back([=](hipStream_t st) { return ssie_launch_product_node(gS, cx, RL, gRL, rl, D, gD, 4, npix, B, st); });
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_product_node(gS, cx, RL, gRL, rl, D, gD, 4, npix, B, st); }));
     }
     CK(build_illum_bwd(b, ops));
     b.mask_axpy(ops, "gRL", "RL_1", MASK_SIGMOID, "G8", pl.B + 1, 0);
@@ -646,6 +660,46 @@ extern "C" int ssie_plan_loss_fwd_bwd(void* h, const float* x, const long* strid
     // loss only: the first three ops of lossbwd are loss_direct, fft_loss, finalize (they also write cotangents)
     for (int i = 0; i < 3; ++i) { int rc = pl->lossbwd[i](st); if (rc) return SSIE_E_LAUNCH; }
     return 0;
+}
+
+// one full compute_loss + backward with a HIP event after every launch: per-kernel-class device time and
+// algorithmic FLOPs of that step (synchronises).  ms/flops/counts have K_NKINDS = 10 entries:
+// {fprop<64>, fprop<32>, wgrad, wgrad_reduce, colsum, pack, loss, fft, attention, elementwise}
+extern "C" int ssie_plan_profile_step(void* h, const float* x, const long* strides4, void* stream,
+                                      double* ms, double* flops, int* counts)
+{
+    Plan* pl = (Plan*)h;
+    if (!pl || !pl->bound || !x || !strides4 || !pl->G || !ms || !flops || !counts) return SSIE_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<const Fn*> seq;
+    for (auto& f : pl->fwd) seq.push_back(&f);
+    for (auto& f : pl->pass2) seq.push_back(&f);
+    for (auto& f : pl->lossbwd) seq.push_back(&f);
+    std::vector<hipEvent_t> ev(seq.size() + 2);
+    for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return SSIE_E_LAUNCH;
+    for (int k = 0; k < K_NKINDS; ++k) { ms[k] = 0; flops[k] = 0; counts[k] = 0; }
+    hipEventRecord(ev[0], st);
+    int rc = pack_all(pl, st);
+    hipEventRecord(ev[1], st);
+    if (!rc) rc = ingest(pl, x, strides4, st);
+    if (!rc && hipMemsetAsync(pl->G, 0, pl->nparam_floats * 4, st) != hipSuccess) rc = SSIE_E_LAUNCH;
+    hipEventRecord(ev[1], st);       // pack only is attributed below; ingest + memset are folded into the first op
+    size_t done = 0;
+    for (; !rc && done < seq.size(); ++done) {
+        if ((*seq[done])(st)) rc = SSIE_E_LAUNCH;
+        hipEventRecord(ev[done + 2], st);
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) rc = SSIE_E_LAUNCH;
+    if (!rc) {
+        float t = 0.f;
+        hipEventElapsedTime(&t, ev[0], ev[1]); ms[K_PACK] += t; counts[K_PACK] += 1;
+        for (size_t i = 0; i < seq.size(); ++i) {
+            hipEventElapsedTime(&t, ev[i + 1], ev[i + 2]);
+            ms[seq[i]->kind] += t; flops[seq[i]->kind] += seq[i]->flops; counts[seq[i]->kind] += 1;
+        }
+    }
+    for (auto& e : ev) hipEventDestroy(e);
+    return rc;
 }
 
 extern "C" int ssie_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n,

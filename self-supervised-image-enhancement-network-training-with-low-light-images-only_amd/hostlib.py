@@ -191,6 +191,8 @@ def _proto():
     L.ssie_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float,
                                  C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]
     L.ssie_fourier_mask.argtypes = [C.c_int, C.c_int, C.c_float, C.c_void_p]
+    L.ssie_plan_profile_step.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_long), C.c_void_p,
+                                         C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
     return L
 
 
@@ -277,6 +279,16 @@ class Plan:
 
     def loss_scalars(self) -> torch.Tensor:
         return self.buffer("scalars").reshape(7)
+
+    KINDS = ("conv_fprop_kernel<2>", "conv_fprop_kernel<1>", "conv_wgrad_kernel", "wgrad_reduce_kernel", "colsum",
+             "pack_weights", "loss_direct", "fft_loss_kernel", "attention", "elementwise")
+
+    def profile_step(self, x):
+        """{kernel class: (device ms, algorithmic FLOPs, launches)} of one loss+backward step (HIP events)."""
+        ms = (C.c_double * 10)(); fl = (C.c_double * 10)(); cnt = (C.c_int * 10)()
+        check(self.L.ssie_plan_profile_step(self.h, x.data_ptr(), self._strides(x), torch.cuda.current_stream().cuda_stream,
+                                            ms, fl, cnt), "ssie_plan_profile_step")
+        return {k: (ms[i], fl[i], cnt[i]) for i, k in enumerate(self.KINDS)}
 
 
 def adam_step(params, grads, m, v, step, lr, grad_scale=1.0, b1=0.9, b2=0.999, eps=1e-8):
