@@ -180,7 +180,7 @@ template __global__ void conv_fprop_kernel<2>(const ConvParams);
 // up to 9 taps x 32x32 accumulators per wave in registers and writes ONE partial slab at the end.
 // ---------------------------------------------------------------------------------------------
 template <int CIB, int COB, int NU>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     constexpr int MI = CIB / 32, NI = COB / 32, NPAIR = MI * NI, WSPLIT = 4 / NPAIR;
@@ -221,6 +221,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
     const int tps = (p.tiles_total + p.nslices - 1) / p.nslices;
     const int tile_beg = slice * tps, tile_end = min(tile_beg + tps, p.tiles_total);
     constexpr int CI4 = CIB / 4, CO4 = COB / 4;
+    // fused bias gradient (column sums of G): done once per co-block by the (ci block 0, tap group 0) workgroups
+    const bool do_bias = p.bias_slabs != nullptr && cib == 0 && blockIdx.z == 0;
+    constexpr int BROWS = 256 / COB;
+    const int bcol = tid % COB, brow = tid / COB;
+    float bsum = 0.f;
 
     for (int tile = tile_beg; tile < tile_end; ++tile) {
         int tt = tile;
@@ -249,8 +254,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
             *(f32x4*)(Gs + pix * COB + 4 * j) = v;
         }
         __syncthreads();
+        if (do_bias)
+            for (int px = brow; px < PT; px += BROWS) bsum += Gs[px * COB + bcol];
         const int npair = PT / 2;
-#pragma unroll 2
         for (int kp = 0; kp < npair; ++kp) {
             const int pix = 2 * kp + h;
             const int xbase = ((pix / SSIE_TW) * p.si * p.hp_w + (pix % SSIE_TW) * p.si) * CIB;
@@ -263,6 +269,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p)
         }
     }
 
+    if (do_bias) {
+        __syncthreads();
+        Gs[brow * COB + bcol] = bsum;
+        __syncthreads();
+        if (tid < COB) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < BROWS; ++r) t += Gs[r * COB + tid];
+            p.bias_slabs[(size_t)slice * p.co_pad + co0 + tid] = t;
+        }
+    }
     // partial slab [slice][tap][ci_pad][co_pad]; row (M) = ci, col (N) = co
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -283,23 +300,39 @@ INST_WGRAD(32, 64, 5) INST_WGRAD(32, 64, 1)
 INST_WGRAD(64, 32, 5) INST_WGRAD(64, 32, 1)
 INST_WGRAD(32, 32, 3) INST_WGRAD(32, 32, 1)
 
-// dst[co*s_co + ci*s_ci + t*s_t] (+)= sum_slices slab[slice][t][ci][co]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int nslices, int ntaps, int ci_pad, int co_pad,
+// dst[co*s_co + ci*s_ci + t*s_t] (+)= sum_slices slab[slice][t][ci][co]; the trailing Cout outputs are the fused
+// bias gradient db[co] (+)= sum_slices bias_slab[slice][co].  64 outputs x 4 slice groups per block, fixed order
+// (deterministic, bit-reproducible across runs and ranks).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int nslices, int ntaps, int ci_pad, int co_pad,
                                     int Cin, int Cout, float* __restrict__ dst, long s_co, long s_ci, long s_t,
-                                    int accumulate)
+                                    const float* __restrict__ bias_slabs, float* __restrict__ db, int accumulate)
 {
-    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    long total = (long)ntaps * Cin * Cout;
-    if (idx >= total) return;
-    int co = (int)(idx % Cout);
-    int ci = (int)((idx / Cout) % Cin);
-    int t = (int)(idx / ((long)Cout * Cin));
-    const size_t slab_sz = (size_t)ntaps * ci_pad * co_pad;
-    const float* sp = slabs + ((size_t)t * ci_pad + ci) * co_pad + co;
+    __shared__ float red[4][64];
+    const int lo = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const long idx = (long)blockIdx.x * 64 + lo;
+    const long total = (long)ntaps * Cin * Cout;
+    const long total_b = total + (bias_slabs ? Cout : 0);
     float sum = 0.f;
-    for (int s = 0; s < nslices; ++s) sum += sp[(size_t)s * slab_sz];
-    float* d = dst + co * s_co + ci * s_ci + t * s_t;
-    *d = accumulate ? (*d + sum) : sum;
+    float* d = nullptr;
+    if (idx < total) {
+        const int co = (int)(idx % Cout);
+        const int ci = (int)((idx / Cout) % Cin);
+        const int t = (int)(idx / ((long)Cout * Cin));
+        const size_t slab_sz = (size_t)ntaps * ci_pad * co_pad;
+        const float* sp = slabs + ((size_t)t * ci_pad + ci) * co_pad + co;
+        for (int s = sg; s < nslices; s += 4) sum += sp[(size_t)s * slab_sz];
+        d = dst + co * s_co + ci * s_ci + t * s_t;
+    } else if (idx < total_b) {
+        const int co = (int)(idx - total);
+        for (int s = sg; s < nslices; s += 4) sum += bias_slabs[(size_t)s * co_pad + co];
+        d = db + co;
+    }
+    red[sg][lo] = sum;
+    __syncthreads();
+    if (sg == 0 && d) {
+        const float tot = (red[0][lo] + red[1][lo]) + (red[2][lo] + red[3][lo]);
+        *d = accumulate ? (*d + tot) : tot;
+    }
 }
 
 // per-channel sums of G over all pixels (bias gradient), two-stage & deterministic
@@ -427,11 +460,12 @@ int ssie_launch_wgrad(const WgradParams& p, hipStream_t st)
 }
 
 int ssie_launch_wgrad_reduce(const float* slabs, int nslices, int ntaps, int ci_pad, int co_pad, int Cin, int Cout,
-                             float* dst, long s_co, long s_ci, long s_t, int accumulate, hipStream_t st)
+                             float* dst, long s_co, long s_ci, long s_t, const float* bias_slabs, float* db,
+                             int accumulate, hipStream_t st)
 {
-    long total = (long)ntaps * Cin * Cout;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                       slabs, nslices, ntaps, ci_pad, co_pad, Cin, Cout, dst, s_co, s_ci, s_t, accumulate);
+    long total = (long)ntaps * Cin * Cout + (bias_slabs ? Cout : 0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st,
+                       slabs, nslices, ntaps, ci_pad, co_pad, Cin, Cout, dst, s_co, s_ci, s_t, bias_slabs, db, accumulate);
     return hipGetLastError() == hipSuccess ? 0 : 25;
 }
 

@@ -24,5 +24,5 @@ int ssie_make_wgrad(WgradParams& p, const SrcDesc& src, int N, int Hv, int Wv, i
                     const TapList& t, float* slabs, int target_wgs);
 size_t ssie_wgrad_slab_floats(const WgradParams& p);
 int ssie_run_wgrad(const SrcDesc& x, int x_creal, int N, int Hv, int Wv, const float* g, int g_cstride, int g_coff, int gC,
-                   int Ho, int Wo, int si, const TapList& t, float* dw, long s_co, long s_ci, long s_t,
+                   int Ho, int Wo, int si, const TapList& t, float* dw, long s_co, long s_ci, long s_t, float* db,
                    int accumulate, float* slabs, size_t slab_cap_floats, hipStream_t st);

@@ -279,15 +279,19 @@ extern "C" int ssie_conv_transpose2d_dgrad(const float* g, int g_cstride, int g_
 }
 
 int ssie_run_wgrad(const SrcDesc& x, int x_creal, int N, int Hv, int Wv, const float* g, int g_cstride, int g_coff, int gC,
-                   int Ho, int Wo, int si, const TapList& t, float* dw, long s_co, long s_ci, long s_t,
+                   int Ho, int Wo, int si, const TapList& t, float* dw, long s_co, long s_ci, long s_t, float* db,
                    int accumulate, float* slabs, size_t slab_cap_floats, hipStream_t st)
 {
     WgradParams p;
     int rc = ssie_make_wgrad(p, x, N, Hv, Wv, 0, g, g_cstride, g_coff, gC, Ho, Wo, si, t, slabs, kTargetWgs);
     if (rc) return rc;
-    if (ssie_wgrad_slab_floats(p) > slab_cap_floats) return SSIE_E_WORKSPACE;
+    const size_t need = ssie_wgrad_slab_floats(p);
+    const size_t bneed = db ? (size_t)p.nslices * p.co_pad : 0;
+    if (need + bneed > slab_cap_floats) return SSIE_E_WORKSPACE;
+    p.bias_slabs = db ? slabs + need : nullptr;
     if (ssie_launch_wgrad(p, st)) return SSIE_E_LAUNCH;
-    if (ssie_launch_wgrad_reduce(slabs, p.nslices, p.ntaps, p.ci_pad, p.co_pad, x_creal, gC, dw, s_co, s_ci, s_t, accumulate, st)) return SSIE_E_LAUNCH;
+    if (ssie_launch_wgrad_reduce(slabs, p.nslices, p.ntaps, p.ci_pad, p.co_pad, x_creal, gC, dw, s_co, s_ci, s_t,
+                                 p.bias_slabs, db, accumulate, st)) return SSIE_E_LAUNCH;
     return 0;
 }
 
@@ -309,10 +313,8 @@ extern "C" int ssie_conv2d_wgrad(const ssie_src_t* src, int N, int Hv, int Wv,
     TapList t = ssie_taps_conv(k);
     int creal = src->C < cin_total - ci_off ? src->C : cin_total - ci_off;
     int rc = ssie_run_wgrad(x, creal, N, Hv, Wv, g, g_cstride, g_coff, cout, Ho, Wo, stride, t,
-                            dw + (size_t)ci_off * T, (long)cin_total * T, T, 1, accumulate, (float*)cur, cap, st);
-    if (rc) return rc;
-    if (db && ssie_launch_colsum(g, (long)N * Ho * Wo, g_cstride, g_coff, cout, partial, 256, db, accumulate, st)) return SSIE_E_LAUNCH;
-    return 0;
+                            dw + (size_t)ci_off * T, (long)cin_total * T, T, 1, db, accumulate, (float*)cur, cap, st);
+    return rc;
 }
 
 extern "C" int ssie_conv_transpose2d_wgrad(const ssie_src_t* x, int N, const float* g, int g_cstride, int g_coff, int cout,
@@ -332,7 +334,7 @@ extern "C" int ssie_conv_transpose2d_wgrad(const ssie_src_t* x, int N, const flo
     TapList t = ssie_taps_conv(3);
     // slab [t][ci' = co][co' = ci]  ->  dw[(ci*cout + co)*9 + t]
     int rc = ssie_run_wgrad(gs, cout, N, 2 * Hin, 2 * Win, x->ptr, x->cstride, x->coff, cin, Hin, Win, 2, t,
-                            dw, /*s_co (co'=ci)*/ (long)cout * 9, /*s_ci (ci'=co)*/ 9, 1, accumulate, (float*)cur, cap, st);
+                            dw, /*s_co (co'=ci)*/ (long)cout * 9, /*s_ci (ci'=co)*/ 9, 1, nullptr, accumulate, (float*)cur, cap, st);
     if (rc) return rc;
     if (db && ssie_launch_colsum(g, (long)N * 4 * Hin * Win, g_cstride, g_coff, cout, partial, 256, db, accumulate, st)) return SSIE_E_LAUNCH;
     return 0;

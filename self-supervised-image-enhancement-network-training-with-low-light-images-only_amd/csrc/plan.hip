@@ -139,7 +139,7 @@ void build_buffers(Plan& pl)
     alloc(pl, "gd2", N, H2, W2, 64); alloc(pl, "Ge2", N, H2, W2, 64); alloc(pl, "gd1", N, H4, W4, 64); alloc(pl, "Ge1", N, H4, W4, 64);
     alloc(pl, "gt3", N, H8, W8, 64); alloc(pl, "gf1", N, H8, W8, 64); alloc(pl, "gao", N, H8, W8, 64); alloc(pl, "gqkv", N, H8, W8, 192);
     // scratch
-    pl.slab_cap = (size_t)kWgs * 9 * 64 * 64 + (size_t)81 * ssie_round_up(B + 1, 64) * 128;
+    pl.slab_cap = (size_t)kWgs * 9 * 64 * 64 + (size_t)81 * ssie_round_up(B + 1, 64) * 128 + (size_t)kWgs * ssie_round_up(B + 1, 64);
     pl.slab_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + pl.slab_cap, 64);
     pl.partial_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 256 * 256, 64);
     pl.loss_blocks = 2048; pl.fft_blocks = ssie_fft_grid(N, B);
@@ -250,7 +250,9 @@ struct Builder {
         return transposed(ops, wbase, L.cout, cs, L.cin * T, T, in, gb.H, gb.W, gx, e);
     }
 
-    int wgrad(std::vector<Fn>& ops, const LayerP& L, int stride, SrcDesc x, int creal, int Hv, int Wv, int ci_off, const char* g, int g_coff = 0)
+    // weight gradient (+ fused bias gradient when with_bias) of a forward conv layer, one input source per call
+    int wgrad(std::vector<Fn>& ops, const LayerP& L, int stride, SrcDesc x, int creal, int Hv, int Wv, int ci_off, const char* g,
+              int g_coff = 0, bool with_bias = false)
     {
         if (dry) return 0;
         const int T = L.k * L.k, pad = (L.k - 1) / 2;
@@ -261,14 +263,18 @@ struct Builder {
         WgradParams p;
         int rc = ssie_make_wgrad(p, x, pl.N, Hv, Wv, 0, pl.buf(g), gb.cs, g_coff, L.cout, Ho, Wo, stride, t, pl.ws + pl.slab_off, kWgs);
         if (rc) return rc;
-        if (ssie_wgrad_slab_floats(p) > pl.slab_cap) return SSIE_E_WORKSPACE;
+        const size_t need = ssie_wgrad_slab_floats(p);
+        if (need + (size_t)p.nslices * p.co_pad > pl.slab_cap) return SSIE_E_WORKSPACE;
         float* dw = pl.G + L.w + (size_t)ci_off * T;
         const long s_co = (long)L.cin * T;
         const float* slabs = pl.ws + pl.slab_off;
         const int cout = L.cout;
+        float* bslab = with_bias ? pl.ws + pl.slab_off + need : nullptr;
+        float* db = with_bias ? pl.G + L.b : nullptr;
+        p.bias_slabs = bslab;
         const double fl = 2.0 * pl.N * Ho * Wo * (double)cout * creal * T;
         ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_wgrad(p, st); }, K_WGRAD, fl));
-        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, p.nslices, p.ntaps, p.ci_pad, p.co_pad, creal, cout, dw, s_co, T, 1, 1, st); }, K_WGRAD_REDUCE));
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, p.nslices, p.ntaps, p.ci_pad, p.co_pad, creal, cout, dw, s_co, T, 1, bslab, db, 1, st); }, K_WGRAD_REDUCE));
         return 0;
     }
 
@@ -370,14 +376,14 @@ int build_decomposition_bwd(Builder& b, std::vector<Fn>& ops, const char* xin, i
     const LayerP Lr = layer(pl, d + "recon"), L7 = layer(pl, d + "conv7.0"), L5 = layer(pl, d + "conv5.0"), Ld = layer(pl, d + "deconv.0", true),
                  L3 = layer(pl, d + "conv3.0"), L2 = layer(pl, d + "conv2.0"), L1 = layer(pl, d + "conv1.0"), Ls = layer(pl, d + "shallow_conv.0"),
                  L0 = layer(pl, d + "conv0.0");
-    CK(b.wgrad(ops, Lr, 1, b.src(c7.c_str(), 64, H, W), 64, H, W, 0, "G8")); b.bias_grad(ops, Lr, "G8");
+    CK(b.wgrad(ops, Lr, 1, b.src(c7.c_str(), 64, H, W), 64, H, W, 0, "G8", 0, true));
     CK(b.dgrad(ops, Lr, 1, "G8", 0, 0, 64, "G7", nullptr, 0, 0));
     CK(b.wgrad(ops, L7, 1, b.src(c5.c_str(), 64, H, W), 64, H, W, 0, "G7"));
-    CK(b.wgrad(ops, L7, 1, b.src(c0.c_str(), 32, H, W), 32, H, W, 64, "G7")); b.bias_grad(ops, L7, "G7");
+    CK(b.wgrad(ops, L7, 1, b.src(c0.c_str(), 32, H, W), 32, H, W, 64, "G7", 0, true));
     CK(b.dgrad(ops, L7, 1, "G7", 0, 0, 64, "G5", c5.c_str(), MASK_RELU, 0));
     CK(b.dgrad(ops, L7, 1, "G7", 0, 64, 32, "G0", c0.c_str(), MASK_RELU, 0));
     CK(b.wgrad(ops, L5, 1, b.src(dc.c_str(), 64, H, W), 64, H, W, 0, "G5"));
-    CK(b.wgrad(ops, L5, 1, b.src(c1.c_str(), 64, H, W), 64, H, W, 64, "G5")); b.bias_grad(ops, L5, "G5");
+    CK(b.wgrad(ops, L5, 1, b.src(c1.c_str(), 64, H, W), 64, H, W, 64, "G5", 0, true));
     CK(b.dgrad(ops, L5, 1, "G5", 0, 0, 64, "Gdc", dc.c_str(), MASK_RELU, 0));
     CK(b.dgrad(ops, L5, 1, "G5", 0, 64, 64, "G1", c1.c_str(), MASK_RELU, 0));
     // ConvTranspose2d: wgrad with swapped roles, dgrad = stride-2 conv of Gdc with W read as OIHW (O = ci, I = co)
@@ -389,7 +395,7 @@ int build_decomposition_bwd(Builder& b, std::vector<Fn>& ops, const char* xin, i
         if (ssie_wgrad_slab_floats(wp) > pl.slab_cap) return SSIE_E_WORKSPACE;
         float* dw = pl.G + Ld.w; const float* slabs = pl.ws + pl.slab_off;
         ops.push_back(Fn([wp](hipStream_t st) { return ssie_launch_wgrad(wp, st); }, K_WGRAD, 2.0 * pl.N * H2 * W2 * 128.0 * 64 * 9));
-        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, wp.nslices, wp.ntaps, wp.ci_pad, wp.co_pad, 64, 128, dw, 64L * 9, 9, 1, 1, st); }, K_WGRAD_REDUCE));
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, wp.nslices, wp.ntaps, wp.ci_pad, wp.co_pad, 64, 128, dw, 64L * 9, 9, 1, nullptr, nullptr, 1, st); }, K_WGRAD_REDUCE));
     }
     b.bias_grad(ops, Ld, "Gdc");
     {
@@ -404,14 +410,14 @@ int build_decomposition_bwd(Builder& b, std::vector<Fn>& ops, const char* xin, i
             b.push(ops, cp, 64);
         }
     }
-    CK(b.wgrad(ops, L3, 1, b.src(c2.c_str(), 128, H2, W2), 128, H2, W2, 0, "G3")); b.bias_grad(ops, L3, "G3");
+    CK(b.wgrad(ops, L3, 1, b.src(c2.c_str(), 128, H2, W2), 128, H2, W2, 0, "G3", 0, true));
     CK(b.dgrad(ops, L3, 1, "G3", 0, 0, 128, "G2", c2.c_str(), MASK_RELU, 0));
-    CK(b.wgrad(ops, L2, 2, b.src(c1.c_str(), 64, H, W), 64, H, W, 0, "G2")); b.bias_grad(ops, L2, "G2");
+    CK(b.wgrad(ops, L2, 2, b.src(c1.c_str(), 64, H, W), 64, H, W, 0, "G2", 0, true));
     CK(b.dgrad(ops, L2, 2, "G2", 0, 0, 64, "G1", c1.c_str(), MASK_RELU, 1));
-    CK(b.wgrad(ops, L1, 1, b.src(sh.c_str(), 64, H, W), 64, H, W, 0, "G1")); b.bias_grad(ops, L1, "G1");
+    CK(b.wgrad(ops, L1, 1, b.src(sh.c_str(), 64, H, W), 64, H, W, 0, "G1", 0, true));
     CK(b.dgrad(ops, L1, 1, "G1", 0, 0, 64, "Gsh", nullptr, 0, 0));
-    CK(b.wgrad(ops, Ls, 1, b.src(xin, pl.CX, H, W), pl.B, H, W, 0, "Gsh")); b.bias_grad(ops, Ls, "Gsh");
-    CK(b.wgrad(ops, L0, 1, b.src(xin, pl.CX, H, W), pl.B, H, W, 0, "G0")); b.bias_grad(ops, L0, "G0");
+    CK(b.wgrad(ops, Ls, 1, b.src(xin, pl.CX, H, W), pl.B, H, W, 0, "Gsh", 0, true));
+    CK(b.wgrad(ops, L0, 1, b.src(xin, pl.CX, H, W), pl.B, H, W, 0, "G0", 0, true));
     if (input_grad) {
         CK(b.dgrad(ops, Ls, 1, "Gsh", 0, 0, pl.B, "gS", nullptr, 0, 1));
         CK(b.dgrad(ops, L0, 1, "G0", 0, 0, pl.B, "gS", nullptr, 0, 1));
@@ -429,30 +435,30 @@ int build_illum_bwd(Builder& b, std::vector<Fn>& ops)
                  Lff1 = layer(pl, i + "attn.ff_linear1"), Lq = layer(pl, i + "attn.q_linear"), Lk = layer(pl, i + "attn.k_linear"),
                  Lv = layer(pl, i + "attn.v_linear"), Lc3 = layer(pl, i + "conv3.0"), Lc2 = layer(pl, i + "conv2.0"),
                  Lc1 = layer(pl, i + "conv1.0"), Lc0 = layer(pl, i + "conv0.0");
-    CK(b.wgrad(ops, Lf, 1, b.src("f", 64, H, W), 64, H, W, 0, "gD")); b.bias_grad(ops, Lf, "gD");
+    CK(b.wgrad(ops, Lf, 1, b.src("f", 64, H, W), 64, H, W, 0, "gD", 0, true));
     CK(b.dgrad(ops, Lf, 1, "gD", 0, 0, 64, "Gf", nullptr, 0, 0));
     CK(b.wgrad(ops, Lu, 1, b.src("d1", 64, H, W), 64, H, W, 0, "Gf"));
     CK(b.wgrad(ops, Lu, 1, b.src("d2", 64, H, W), 64, H, W, 64, "Gf"));
-    CK(b.wgrad(ops, Lu, 1, b.src("d3", 64, H, W), 64, H, W, 128, "Gf")); b.bias_grad(ops, Lu, "Gf");
+    CK(b.wgrad(ops, Lu, 1, b.src("d3", 64, H, W), 64, H, W, 128, "Gf", 0, true));
     CK(b.dgrad(ops, Lu, 1, "Gf", 0, 128, 64, "gd3", nullptr, 0, 0));
     CK(b.dgrad(ops, Lu, 1, "Gf", 0, 64, 64, "tmpH", nullptr, 0, 0)); b.upadj(ops, "tmpH", H, W, "gd2", 0);
     CK(b.dgrad(ops, Lu, 1, "Gf", 0, 0, 64, "tmpH", nullptr, 0, 0)); b.upadj(ops, "tmpH", H, W, "gd1", 0);
     // level H: d3 = relu(e3) + a0
     b.mask_axpy(ops, "gd3", "u3", MASK_RELU, "Ge3", 64, 0);
-    CK(b.wgrad(ops, Ld3, 1, b.src("d2", 64, H, W), 64, H, W, 0, "Ge3")); b.bias_grad(ops, Ld3, "Ge3");
+    CK(b.wgrad(ops, Ld3, 1, b.src("d2", 64, H, W), 64, H, W, 0, "Ge3", 0, true));
     CK(b.dgrad(ops, Ld3, 1, "Ge3", 0, 0, 64, "tmpH", nullptr, 0, 0)); b.upadj(ops, "tmpH", H, W, "gd2", 1);
     // level H/2: d2 = relu(e2) + a1.  tmpH is reused with the (H2, W2) geometry through a view buffer
     b.mask_axpy(ops, "gd2", "u2", MASK_RELU, "Ge2", 64, 0);
-    CK(b.wgrad(ops, Ld2, 1, b.src("d1", 64, H2, W2), 64, H2, W2, 0, "Ge2")); b.bias_grad(ops, Ld2, "Ge2");
+    CK(b.wgrad(ops, Ld2, 1, b.src("d1", 64, H2, W2), 64, H2, W2, 0, "Ge2", 0, true));
     CK(b.dgrad(ops, Ld2, 1, "Ge2", 0, 0, 64, "tmpH2", nullptr, 0, 0)); b.upadj(ops, "tmpH2", H2, W2, "gd1", 1);
     // level H/4
     b.mask_axpy(ops, "gd1", "u1", MASK_RELU, "Ge1", 64, 0);
-    CK(b.wgrad(ops, Ld1, 1, b.src("t3", 64, H4, W4), 64, H4, W4, 0, "Ge1")); b.bias_grad(ops, Ld1, "Ge1");
+    CK(b.wgrad(ops, Ld1, 1, b.src("t3", 64, H4, W4), 64, H4, W4, 0, "Ge1", 0, true));
     CK(b.dgrad(ops, Ld1, 1, "Ge1", 0, 0, 64, "tmpH4", nullptr, 0, 0)); b.upadj(ops, "tmpH4", H4, W4, "gt3", 0);
     // TransformerBlock backward: t3 = a3 + ff2(relu(ff1(attn(q,k,v(a3)))))
-    CK(b.wgrad(ops, Lff2, 1, b.src("f1", 64, H8, W8), 64, H8, W8, 0, "gt3")); b.bias_grad(ops, Lff2, "gt3");
+    CK(b.wgrad(ops, Lff2, 1, b.src("f1", 64, H8, W8), 64, H8, W8, 0, "gt3", 0, true));
     CK(b.dgrad(ops, Lff2, 1, "gt3", 0, 0, 64, "gf1", "f1", MASK_RELU, 0));
-    CK(b.wgrad(ops, Lff1, 1, b.src("ao", 64, H8, W8), 64, H8, W8, 0, "gf1")); b.bias_grad(ops, Lff1, "gf1");
+    CK(b.wgrad(ops, Lff1, 1, b.src("ao", 64, H8, W8), 64, H8, W8, 0, "gf1", 0, true));
     CK(b.dgrad(ops, Lff1, 1, "gf1", 0, 0, 64, "gao", nullptr, 0, 0));
     if (!b.dry) {
         const float* qkv = pl.buf("qkv"); const float* ao = pl.buf("ao"); const float* gao = pl.buf("gao");
@@ -460,23 +466,23 @@ int build_illum_bwd(Builder& b, std::vector<Fn>& ops)
         const int N = pl.N, T = H8 * W8;
         ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_attn_bwd(qkv, 192, ao, gao, 64, lse, delta, gqkv, N, T, st); }, K_ATTN, 8.0 * N * 4 * (double)T * T * 16));
     }
-    CK(b.wgrad(ops, Lq, 1, b.src("a3", 64, H8, W8), 64, H8, W8, 0, "gqkv", 0)); b.bias_grad(ops, Lq, "gqkv", 0);
-    CK(b.wgrad(ops, Lk, 1, b.src("a3", 64, H8, W8), 64, H8, W8, 0, "gqkv", 64)); b.bias_grad(ops, Lk, "gqkv", 64);
-    CK(b.wgrad(ops, Lv, 1, b.src("a3", 64, H8, W8), 64, H8, W8, 0, "gqkv", 128)); b.bias_grad(ops, Lv, "gqkv", 128);
+    CK(b.wgrad(ops, Lq, 1, b.src("a3", 64, H8, W8), 64, H8, W8, 0, "gqkv", 0, true));
+    CK(b.wgrad(ops, Lk, 1, b.src("a3", 64, H8, W8), 64, H8, W8, 0, "gqkv", 64, true));
+    CK(b.wgrad(ops, Lv, 1, b.src("a3", 64, H8, W8), 64, H8, W8, 0, "gqkv", 128, true));
     // g(a3) = [gt3 + dgrad_q + dgrad_k + dgrad_v] * relu'(a3)
     b.mask_axpy(ops, "gt3", "a3", MASK_RELU, "gt3", 64, 0);
     CK(b.dgrad(ops, Lq, 1, "gqkv", 0, 0, 64, "gt3", "a3", MASK_RELU, 1));
     CK(b.dgrad(ops, Lk, 1, "gqkv", 64, 0, 64, "gt3", "a3", MASK_RELU, 1));
     CK(b.dgrad(ops, Lv, 1, "gqkv", 128, 0, 64, "gt3", "a3", MASK_RELU, 1));
-    CK(b.wgrad(ops, Lc3, 2, b.src("a2", 64, H4, W4), 64, H4, W4, 0, "gt3")); b.bias_grad(ops, Lc3, "gt3");
+    CK(b.wgrad(ops, Lc3, 2, b.src("a2", 64, H4, W4), 64, H4, W4, 0, "gt3", 0, true));
     b.mask_axpy(ops, "gd1", "a2", MASK_RELU, "gd1", 64, 0);
     CK(b.dgrad(ops, Lc3, 2, "gt3", 0, 0, 64, "gd1", "a2", MASK_RELU, 1));
-    CK(b.wgrad(ops, Lc2, 2, b.src("a1", 64, H2, W2), 64, H2, W2, 0, "gd1")); b.bias_grad(ops, Lc2, "gd1");
+    CK(b.wgrad(ops, Lc2, 2, b.src("a1", 64, H2, W2), 64, H2, W2, 0, "gd1", 0, true));
     b.mask_axpy(ops, "gd2", "a1", MASK_RELU, "gd2", 64, 0);
     CK(b.dgrad(ops, Lc2, 2, "gd1", 0, 0, 64, "gd2", "a1", MASK_RELU, 1));
-    CK(b.wgrad(ops, Lc1, 2, b.src("a0", 64, H, W), 64, H, W, 0, "gd2")); b.bias_grad(ops, Lc1, "gd2");
+    CK(b.wgrad(ops, Lc1, 2, b.src("a0", 64, H, W), 64, H, W, 0, "gd2", 0, true));
     CK(b.dgrad(ops, Lc1, 2, "gd2", 0, 0, 64, "gd3", nullptr, 0, 1));
-    CK(b.wgrad(ops, Lc0, 1, b.src("RL_1", pl.CRL, H, W), pl.B + 1, H, W, 0, "gd3")); b.bias_grad(ops, Lc0, "gd3");
+    CK(b.wgrad(ops, Lc0, 1, b.src("RL_1", pl.CRL, H, W), pl.B + 1, H, W, 0, "gd3", 0, true));
     CK(b.dgrad(ops, Lc0, 1, "gd3", 0, 0, pl.B + 1, "gRL", nullptr, 0, 1));
     return 0;
 }

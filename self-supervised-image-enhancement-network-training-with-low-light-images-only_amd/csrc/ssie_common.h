@@ -74,6 +74,7 @@ struct WgradParams {
     int8_t tap_dy[SSIE_MAX_TAPS];
     int8_t tap_dx[SSIE_MAX_TAPS];
     float* slabs;           // [slice][tap][ci_pad][co_pad]
+    float* bias_slabs;      // optional [slice][co_pad]: fused bias gradient (column sums of g)
     int ci_pad, co_pad;
     int nslices, tiles_total, tiles_y, tiles_x, th;
     int ci_blocks, co_blocks, tap_groups;
@@ -90,7 +91,8 @@ struct PackDesc {
 int ssie_launch_fprop(const ConvParams& p, hipStream_t st);
 int ssie_launch_wgrad(const WgradParams& p, hipStream_t st);
 int ssie_launch_wgrad_reduce(const float* slabs, int nslices, int ntaps, int ci_pad, int co_pad, int Cin, int Cout,
-                             float* dst, long s_co, long s_ci, long s_t, int accumulate, hipStream_t st);
+                             float* dst, long s_co, long s_ci, long s_t, const float* bias_slabs, float* db,
+                             int accumulate, hipStream_t st);
 int ssie_launch_colsum(const float* g, long npix, int cstride, int coff, int C, float* partial, int nblk,
                        float* dst, int accumulate, hipStream_t st);
 int ssie_launch_pack(const PackDesc& d, hipStream_t st);
