@@ -17,70 +17,106 @@
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// Diagnostic build only (-DSSIE_STAMP, tools/stamp_conv.py): per-workgroup s_memtime stamps of the fprop phases,
+// written to a buffer of their own.  The shipped library never executes a stamp.
+#ifdef SSIE_STAMP
+__device__ unsigned long long* ssie_stamp_buf = nullptr;
+extern "C" int ssie_debug_set_stamp_buffer(void* buf)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(ssie_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+#define STAMP(k) do { if (ssie_stamp_buf && threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    ssie_stamp_buf[(size_t)blockIdx.x * 8 + (k)] = t_; } } while (0)
+#define STAMP_DECL unsigned long long st_loop_ = 0, st_epi_ = 0, st_t_ = 0, st_n_ = 0;
+#define STAMP_T0 do { st_t_ = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP_ACC(var) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); var += t_ - st_t_; st_t_ = t_; } while (0)
+#define STAMP_FLUSH do { if (ssie_stamp_buf && threadIdx.x == 0) { ssie_stamp_buf[(size_t)blockIdx.x * 8 + 2] = st_loop_; \
+    ssie_stamp_buf[(size_t)blockIdx.x * 8 + 5] = st_epi_; ssie_stamp_buf[(size_t)blockIdx.x * 8 + 6] = st_n_; } } while (0)
+#else
+#define STAMP(k)
+#define STAMP_DECL
+#define STAMP_T0
+#define STAMP_ACC(var)
+#define STAMP_FLUSH
+#endif
+
 __device__ __forceinline__ int ssie_swz(int hp) { return (hp >> 2) & 3; }
 
 struct SrcSel {
     const float* ptr; int C, cstride, coff, Hs, Ws; float sy, sx; int cbeg;
 };
 
-// select the source holding virtual channel c_first (uniform); explicit selects keep the
-// by-value kernarg struct out of scratch memory.
-__device__ __forceinline__ SrcSel ssie_pick_src(const SrcDesc* src, int nsrc, int c_first)
+// Picking the source of a chunk must not index the by-value kernarg struct at run time (hipcc then spills
+// the whole 470-byte struct to scratch) and must not select between loads either (instcombine folds that
+// back into a load of a selected ADDRESS).  So the three descriptors are blended arithmetically:
+// v = v0 + m1*(v1-v0) + m2*(v2-v1), m1 = [which >= 1], m2 = [which == 2] - a few scalar integer ops per chunk.
+template <typename PT>
+__device__ __forceinline__ SrcSel ssie_pick_src(const PT& p, int c_first)
 {
+    const int c1 = p.src[0].C, c2 = p.src[0].C + p.src[1].C;
+    const int m1 = (p.nsrc > 1 && c_first >= c1) ? 1 : 0;
+    const int m2 = (p.nsrc > 2 && c_first >= c2) ? 1 : 0;
+    auto bl = [&](int v0, int v1, int v2) { return v0 + m1 * (v1 - v0) + m2 * (v2 - v1); };
     SrcSel r;
-    int s = 0, cbeg = 0;
-    if (nsrc > 1 && c_first >= src[0].C) { s = 1; cbeg = src[0].C; }
-    if (nsrc > 2 && c_first >= src[0].C + src[1].C) { s = 2; cbeg = src[0].C + src[1].C; }
-    r.ptr = s == 0 ? src[0].ptr : (s == 1 ? src[1].ptr : src[2].ptr);
-    r.C = s == 0 ? src[0].C : (s == 1 ? src[1].C : src[2].C);
-    r.cstride = s == 0 ? src[0].cstride : (s == 1 ? src[1].cstride : src[2].cstride);
-    r.coff = s == 0 ? src[0].coff : (s == 1 ? src[1].coff : src[2].coff);
-    r.Hs = s == 0 ? src[0].Hs : (s == 1 ? src[1].Hs : src[2].Hs);
-    r.Ws = s == 0 ? src[0].Ws : (s == 1 ? src[1].Ws : src[2].Ws);
-    r.sy = s == 0 ? src[0].sy : (s == 1 ? src[1].sy : src[2].sy);
-    r.sx = s == 0 ? src[0].sx : (s == 1 ? src[1].sx : src[2].sx);
-    r.cbeg = cbeg;
+    const long long q0 = (long long)p.src[0].ptr, q1 = (long long)p.src[1].ptr, q2 = (long long)p.src[2].ptr;
+    r.ptr = (const float*)(q0 + m1 * (q1 - q0) + m2 * (q2 - q1));
+    r.C = bl(p.src[0].C, p.src[1].C, p.src[2].C);
+    r.cstride = bl(p.src[0].cstride, p.src[1].cstride, p.src[2].cstride);
+    r.coff = bl(p.src[0].coff, p.src[1].coff, p.src[2].coff);
+    r.Hs = bl(p.src[0].Hs, p.src[1].Hs, p.src[2].Hs);
+    r.Ws = bl(p.src[0].Ws, p.src[1].Ws, p.src[2].Ws);
+    r.sy = __int_as_float(bl(__float_as_int(p.src[0].sy), __float_as_int(p.src[1].sy), __float_as_int(p.src[2].sy)));
+    r.sx = __int_as_float(bl(__float_as_int(p.src[0].sx), __float_as_int(p.src[1].sx), __float_as_int(p.src[2].sx)));
+    r.cbeg = m1 * c1 + m2 * (c2 - c1);
     return r;
 }
 
-// load 4 consecutive channels of virtual pixel (n, vy, vx); zero outside the image / channel range
+// load 4 consecutive channels of virtual pixel (n, vy, vx); zero outside the image / channel range.
+// Branch-free: the address is clamped into the tensor and the value is zeroed afterwards, so a batch of these
+// compiles to back-to-back global_load_dwordx4 without exec-mask regions (hipcc serialises predicated loads
+// with s_waitcnt vmcnt(0) between them).
 __device__ __forceinline__ f32x4 ssie_load_virtual(const SrcSel& s, int n, int vy, int vx, int Hv, int Wv, int c)
 {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (vy >= 0 && vy < Hv && vx >= 0 && vx < Wv && c < s.C) {
-        int y = min((int)floorf((float)vy * s.sy), s.Hs - 1);
-        int x = min((int)floorf((float)vx * s.sx), s.Ws - 1);
-        v = *(const f32x4*)(s.ptr + ((size_t)(n * s.Hs + y) * s.Ws + x) * s.cstride + s.coff + c);
-    }
-    return v;
+    const bool ok = vy >= 0 && vy < Hv && vx >= 0 && vx < Wv && c < s.C;
+    const int cy = min(max(vy, 0), Hv - 1), cx = min(max(vx, 0), Wv - 1), cc = min(c, s.C - 4);
+    const int y = min((int)floorf((float)cy * s.sy), s.Hs - 1);
+    const int x = min((int)floorf((float)cx * s.sx), s.Ws - 1);
+    f32x4 v = *(const f32x4*)(s.ptr + ((size_t)(n * s.Hs + y) * s.Ws + x) * s.cstride + s.coff + cc);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    return ok ? v : z;
 }
 
 // ---------------------------------------------------------------------------------------------
 // fprop / dgrad
 // ---------------------------------------------------------------------------------------------
-template <int NT>   // output-channel tile = 32*NT
-__global__ __launch_bounds__(256) void conv_fprop_kernel(const ConvParams p)
+// NT: output-channel tile = 32*NT.  NA: max float4 A-loads per thread per chunk (halo tile size / 256).
+// Staging is software-pipelined through registers: the global loads of step s+1 (next tap group / next
+// 16-channel chunk) are issued right after the barrier that publishes step s and land while the MFMAs of
+// step s run; only the short register -> LDS commit sits between two barriers.
+// TH: output tile rows (8 or 16; the tile is TH x 16 positions = TH/2 MFMA M-tiles).  The 16-row tile halves the
+// weight staging, the barriers and the tile boundaries per MFMA and is used for the stride-1 3x3 / 1x1 layers.
+template <int NT, int NA, int TH>
+__global__ __launch_bounds__(256, ((NA <= 3 && TH == 8) ? 3 : 2)) void conv_fprop_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     constexpr int BN = 32 * NT;
-    constexpr int MT = (NT == 1) ? 1 : 2;
+    constexpr int MT = (NT == 1) ? TH / 8 : TH / 4;
+    constexpr int NB = (SSIE_TG * 4 * BN + 255) / 256;
     const int HP = p.hp_h * p.hp_w;
     f32x4* As = (f32x4*)smem_f;                // [HP][4] float4 (16-B slot XOR-swizzled)
     f32x4* Bs = As + HP * 4;                   // [TG*4][BN] float4
     int* tapoff = (int*)(Bs + SSIE_TG * 4 * BN);
+    int* s_next = tapoff + SSIE_MAX_TAPS;      // dynamic tile scheduler hand-off slot
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, li = lane & 31;
-    int bid = blockIdx.x;
-    const int cob = bid % p.co_blocks; bid /= p.co_blocks;
-    const int tx = bid % p.tiles_x; bid /= p.tiles_x;
-    const int ty = bid % p.tiles_y;
-    const int n = bid / p.tiles_y;
-    const int a0 = ty * SSIE_TH, b0 = tx * SSIE_TW;
-    const int co0 = cob * BN;
     const int wn = (NT == 1) ? 0 : (wave & 1);
     const int wm = (NT == 1) ? wave : (wave >> 1);
 
+    STAMP(0);
+#ifdef SSIE_STAMP
+    if (ssie_stamp_buf && threadIdx.x == 0) ssie_stamp_buf[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int t = tid; t < p.ntaps; t += 256)
         tapoff[t] = ((int)p.tap_dy[t] - p.min_dy) * p.hp_w + ((int)p.tap_dx[t] - p.min_dx);
 
@@ -90,88 +126,216 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const ConvParams p)
         int mt = wm * MT + m;
         pixbase[m] = ((2 * mt + (li >> 4)) * p.si) * p.hp_w + (li & 15) * p.si;
     }
-    f32x16 acc[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-
     const int ngroups = (p.ntaps + SSIE_TG - 1) / SSIE_TG;
-    const int vy0 = a0 * p.si + p.min_dy, vx0 = b0 * p.si + p.min_dx;
+    const int nsteps = p.nchunks * ngroups;
+    const int HP4 = HP * 4;
+    const int total_tiles = p.N * p.tiles_y * p.tiles_x * p.co_blocks;
 
-    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-        const SrcSel s = ssie_pick_src(p.src, p.nsrc, chunk * SSIE_CK);
-        for (int g = 0; g < ngroups; ++g) {
-            __syncthreads();     // everyone finished reading the previous B (and A when g == 0)
-            if (g == 0) {
-                for (int id = tid; id < HP * 4; id += 256) {
-                    int pix = id >> 2, j = id & 3;
-                    int hy = pix / p.hp_w, hx = pix - hy * p.hp_w;
-                    f32x4 v = ssie_load_virtual(s, n, vy0 + hy, vx0 + hx, p.Hv, p.Wv,
-                                                chunk * SSIE_CK + 4 * j - s.cbeg);
-                    As[pix * 4 + (j ^ ssie_swz(pix))] = v;
-                }
-            }
+    // tile index -> (image n, tile row/col, output-channel block); co block fastest so the workgroups that share
+    // an input halo tile run next to each other
+#define SSIE_DECODE(T, N_, A0_, B0_, CO0_)                                                \
+    {                                                                                     \
+        int q_ = (T);                                                                     \
+        CO0_ = (q_ % p.co_blocks) * BN; q_ /= p.co_blocks;                                \
+        B0_ = (q_ % p.tiles_x) * SSIE_TW; q_ /= p.tiles_x;                                \
+        A0_ = (q_ % p.tiles_y) * TH; N_ = q_ / p.tiles_y;                            \
+    }
+
+    // halo pixel of each of this thread's A loads (tile-invariant: hoisted out of the prefetch)
+    int ahy[NA], ahx[NA], aj[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int id = min(tid + i * 256, HP4 - 1);
+        const int pix = id >> 2;
+        ahy[i] = pix / p.hp_w; ahx[i] = pix - ahy[i] * p.hp_w; aj[i] = id & 3;
+    }
+    f32x4 pa[NA], pb[NB];
+#define SSIE_PREFETCH(CHUNK, G, N_, A0_, B0_, CO0_)                                                          \
+    {                                                                                                        \
+        if ((G) == 0) {                                                                                      \
+            const SrcSel s_ = ssie_pick_src(p, (CHUNK) * SSIE_CK);                                           \
+            const int vy0_ = (A0_) * p.si + p.min_dy, vx0_ = (B0_) * p.si + p.min_dx;                        \
+            _Pragma("unroll") for (int i_ = 0; i_ < NA; ++i_)                                                \
+                pa[i_] = ssie_load_virtual(s_, (N_), vy0_ + ahy[i_], vx0_ + ahx[i_], p.Hv, p.Wv,             \
+                                           (CHUNK) * SSIE_CK + 4 * aj[i_] - s_.cbeg);                        \
+        }                                                                                                    \
+        /* weights: always TG tap-rows (the packed buffer is padded by one tap group, so the over-read past a  \
+           short group stays inside the allocation; only the valid rows are committed to LDS) */             \
+        const f32x4* wsrc_ = (const f32x4*)p.wpacked + ((size_t)((CHUNK) * p.ntaps + (G) * SSIE_TG) * 4) * p.Cout_pad  \
+                             + (CO0_) + (size_t)(tid / BN) * p.Cout_pad + (tid % BN);                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < NB; ++i_) pb[i_] = wsrc_[(size_t)i_ * (256 / BN) * p.Cout_pad]; \
+    }
+
+    // Persistent workgroups with a dynamic tile queue: the first tile is blockIdx.x, every further one is drawn
+    // from a device counter (zeroed by the host before the launch), so workgroups that get more of the shared
+    // MFMA pipe (older waves win arbitration) simply take more tiles and all finish together.  The counter value
+    // is fetched by one lane a whole step ahead of its use and handed to the workgroup through LDS between the two
+    // barriers every step has anyway.  The first loads of the NEXT tile are issued before the epilogue of the current
+    // one, so a tile boundary costs one register->LDS commit instead of a cold global-memory round trip.
+    int tile = blockIdx.x;
+    if (tile >= total_tiles) return;
+    int n, a0, b0, co0;
+    SSIE_DECODE(tile, n, a0, b0, co0)
+    SSIE_PREFETCH(0, 0, n, a0, b0, co0)
+    bool first = true;
+    const int pub_step = nsteps > 1 ? 1 : 0;
+    int fetched = 0x7fffffff;
+    STAMP_DECL
+    while (tile < total_tiles) {
+        STAMP_T0;
+        f32x16 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        int ntile = 0x7fffffff;
+        int nn = n, na0 = a0, nb0 = b0, nco0 = co0;
+
+        int chunk = 0, g = 0;
+        for (int step = 0; step < nsteps; ++step) {
             const int t0 = g * SSIE_TG;
             const int tg = min(SSIE_TG, p.ntaps - t0);
-            {
-                const f32x4* wsrc = (const f32x4*)p.wpacked
-                    + ((size_t)(chunk * p.ntaps + t0) * 4) * p.Cout_pad + co0;
-                for (int id = tid; id < tg * 4 * BN; id += 256) {
-                    int row = id / BN, col = id % BN;
-                    Bs[id] = wsrc[(size_t)row * p.Cout_pad + col];
+#ifndef ABL_NOBARRIER
+            __syncthreads();     // everyone finished reading the previous B (and A when g == 0)
+#endif
+#ifndef ABL_NOCOMMIT
+            if (g == 0) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    const int id = tid + i * 256;
+                    if (id < HP4) { const int pix = id >> 2, j = id & 3; As[pix * 4 + (j ^ ssie_swz(pix))] = pa[i]; }
                 }
             }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int id = tid + i * 256;
+                if (id < tg * 4 * BN) Bs[id] = pb[i];
+            }
+#endif
+            if (tid == 0) {
+                if (step == 0 && (nsteps == 1 || !p.tile_counter))
+                    fetched = p.tile_counter ? (int)gridDim.x + atomicAdd(p.tile_counter, 1) : tile + (int)gridDim.x;
+                if (step == pub_step) *s_next = fetched;
+            }
+#ifndef ABL_NOBARRIER
             __syncthreads();
-            for (int tl = 0; tl < tg; ++tl) {
-                const int off = tapoff[t0 + tl];
+#endif
+            if (first && step == 0) { STAMP(1); first = false; }
+            if (tid == 0 && step == 0 && nsteps > 1 && p.tile_counter)
+                fetched = (int)gridDim.x + atomicAdd(p.tile_counter, 1);      // consumed one step later
+            if (step == pub_step) {
+                ntile = *s_next;
+                if (ntile < total_tiles) SSIE_DECODE(ntile, nn, na0, nb0, nco0)
+            }
+            int nchunk = chunk, ng = g + 1;
+            if (ng == ngroups) { ng = 0; ++nchunk; }
+#ifndef ABL_NOPREFETCH
+            if (step + 1 < nsteps) SSIE_PREFETCH(nchunk, ng, n, a0, b0, co0)
+            else if (ntile < total_tiles) SSIE_PREFETCH(0, 0, nn, na0, nb0, nco0)
+#endif
+            // Software-pipelined fragment reads: two register sets (X for kq = 0, Y for kq = 1).  The ds_reads of the
+            // next half-tap are issued BEFORE the MFMAs of the current one, so one wave alone keeps its SIMD's MFMA
+            // pipe busy across the ~100-cycle LDS latency (counted lgkmcnt waits instead of a drain per 4 MFMAs).
+#define SSIE_LDFRAG(BF, AF, TL, KQ, OFF)                                                              \
+            {                                                                                             \
+                BF = Bs[((TL) * 4 + (KQ) * 2 + h) * BN + wn * 32 + li];                                   \
+                _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_) {                                       \
+                    const int hp_ = pixbase[m_] + (OFF);                                                  \
+                    AF[m_] = As[hp_ * 4 + (((KQ) * 2 + h) ^ ssie_swz(hp_))];                              \
+                }                                                                                         \
+            }
+#define SSIE_MFMA4(BF, AF)                                                                            \
+            _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_) {                                           \
+                acc[m_] = MFMA32(AF[m_].x, BF.x, acc[m_]); acc[m_] = MFMA32(AF[m_].y, BF.y, acc[m_]);     \
+                acc[m_] = MFMA32(AF[m_].z, BF.z, acc[m_]); acc[m_] = MFMA32(AF[m_].w, BF.w, acc[m_]);     \
+            }
+            {
+                f32x4 bX, bY, aX[MT], aY[MT];
+                int off = tapoff[t0];
+                SSIE_LDFRAG(bX, aX, 0, 0, off)
+                for (int tl = 0; tl < tg; ++tl) {
+                    const int off_next = tapoff[t0 + min(tl + 1, tg - 1)];
+                    SSIE_LDFRAG(bY, aY, tl, 1, off)
+                    SSIE_MFMA4(bX, aX)
+                    if (tl + 1 < tg) SSIE_LDFRAG(bX, aX, tl + 1, 0, off_next)
+                    SSIE_MFMA4(bY, aY)
+                    off = off_next;
+                }
+            }
+#undef SSIE_LDFRAG
+#undef SSIE_MFMA4
+            chunk = nchunk; g = ng;
+        }
+
+        STAMP_ACC(st_loop_);
+        // epilogue: C/D layout col = lane&31 (channel), row i = (r&3) + 8*(r>>2) + 4*(lane>>5) (position inside the
+        // 2x16 M-tile: tile row i>>4 = r>>3, tile column i&15 = (r&3) + 8*((r>>2)&1) + 4h).  All per-element address
+        // arithmetic is therefore a compile-time multiple of two run-time strides; the common case (interior tile,
+        // plain bias+activation store) is a straight run of 16 stores per M-tile.
+        const int co = co0 + wn * 32 + li;
+        if (co < p.Cout) {
+            const float bv = p.bias ? p.bias[co] : 0.f;
+            const long rowstride = (long)p.so * p.Wout * p.out_cstride;
+            const long pixstride = (long)p.so * p.out_cstride;
+            const bool simple = p.mask_mode == MASK_NONE && !p.out2 && !p.addsrc && !p.accumulate;
+            const bool full = a0 + TH <= p.Ho && b0 + SSIE_TW <= p.Wo &&
+                              (a0 + TH - 1) * p.so + p.py < p.Hout && (b0 + SSIE_TW - 1) * p.so + p.px < p.Wout;
 #pragma unroll
-                for (int kq = 0; kq < 2; ++kq) {
-                    const f32x4 b = Bs[(tl * 4 + kq * 2 + h) * BN + wn * 32 + li];
+            for (int m = 0; m < MT; ++m) {
+                const int mt = wm * MT + m;
+                const int arow = a0 + 2 * mt, bcol = b0 + 4 * h;
+                const size_t o0 = ((size_t)(n * p.Hout + arow * p.so + p.py) * p.Wout + bcol * p.so + p.px) * p.out_cstride + p.out_coff + co;
+                if (simple && full) {
+                    float* ob = p.out + o0;
+                    if (p.act == ACT_RELU) {
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        const int hp = pixbase[m] + off;
-                        const f32x4 a = As[hp * 4 + ((kq * 2 + h) ^ ssie_swz(hp))];
-                        acc[m] = MFMA32(a.x, b.x, acc[m]);
-                        acc[m] = MFMA32(a.y, b.y, acc[m]);
-                        acc[m] = MFMA32(a.z, b.z, acc[m]);
-                        acc[m] = MFMA32(a.w, b.w, acc[m]);
+                        for (int r = 0; r < 16; ++r) ob[(r >> 3) * rowstride + ((r & 3) + 8 * ((r >> 2) & 1)) * pixstride] = fmaxf(acc[m][r] + bv, 0.f);
+                    } else if (p.act == ACT_NONE) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) ob[(r >> 3) * rowstride + ((r & 3) + 8 * ((r >> 2) & 1)) * pixstride] = acc[m][r] + bv;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) ob[(r >> 3) * rowstride + ((r & 3) + 8 * ((r >> 2) & 1)) * pixstride] = 1.f / (1.f + expf(-(acc[m][r] + bv)));
                     }
+                    continue;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int tr = r >> 3, tc = (r & 3) + 8 * ((r >> 2) & 1);
+                    const int a = arow + tr, b = bcol + tc;
+                    if (a >= p.Ho || b >= p.Wo) continue;
+                    if (a * p.so + p.py >= p.Hout || b * p.so + p.px >= p.Wout) continue;
+                    const size_t o = o0 + tr * rowstride + tc * pixstride;
+                    float v = acc[m][r] + bv;
+                    if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (p.act == ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+                    if (p.mask_mode == MASK_RELU) v = p.mask_y[o] > 0.f ? v : 0.f;
+                    else if (p.mask_mode == MASK_SIGMOID) { float y = p.mask_y[o]; v *= y * (1.f - y); }
+                    if (p.out2) p.out2[o] = v;
+                    if (p.addsrc) v += p.addsrc[o];
+                    if (p.accumulate) v += p.out[o];
+                    p.out[o] = v;
                 }
             }
         }
+        n = nn; a0 = na0; b0 = nb0; co0 = nco0; tile = ntile;
+        STAMP_ACC(st_epi_);
+#ifdef SSIE_STAMP
+        st_n_ += 1;
+#endif
     }
-
-    // epilogue: C/D layout col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (position)
-    const int co = co0 + wn * 32 + li;
-    if (co >= p.Cout) return;
-    const float bv = p.bias ? p.bias[co] : 0.f;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int mt = wm * MT + m;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int a = a0 + 2 * mt + (i >> 4), b = b0 + (i & 15);
-            if (a >= p.Ho || b >= p.Wo) continue;
-            const int oy = a * p.so + p.py, ox = b * p.so + p.px;
-            if (oy >= p.Hout || ox >= p.Wout) continue;
-            const size_t o = ((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.out_cstride + p.out_coff + co;
-            float v = acc[m][r] + bv;
-            if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-            else if (p.act == ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
-            if (p.mask_mode == MASK_RELU) v = p.mask_y[o] > 0.f ? v : 0.f;
-            else if (p.mask_mode == MASK_SIGMOID) { float y = p.mask_y[o]; v *= y * (1.f - y); }
-            if (p.out2) p.out2[o] = v;
-            if (p.addsrc) v += p.addsrc[o];
-            if (p.accumulate) v += p.out[o];
-            p.out[o] = v;
-        }
-    }
+    STAMP_FLUSH;
+#ifdef SSIE_STAMP
+    if (ssie_stamp_buf && threadIdx.x == 0) ssie_stamp_buf[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime() - ssie_stamp_buf[(size_t)blockIdx.x * 8 + 7];
+#endif
+#undef SSIE_PREFETCH
+#undef SSIE_DECODE
+    STAMP(3);
 }
 
-template __global__ void conv_fprop_kernel<1>(const ConvParams);
-template __global__ void conv_fprop_kernel<2>(const ConvParams);
+#define INST_FPROP(NT, NA, TH) template __global__ void conv_fprop_kernel<NT, NA, TH>(const ConvParams);
+INST_FPROP(1, 3, 8) INST_FPROP(1, 6, 8) INST_FPROP(1, 9, 8) INST_FPROP(2, 3, 8) INST_FPROP(2, 6, 8) INST_FPROP(2, 9, 8)
+INST_FPROP(1, 6, 16) INST_FPROP(2, 6, 16)
 
 // ---------------------------------------------------------------------------------------------
 // wgrad: dW[tap][ci][co] = sum_positions X[pos*si + tap][ci] * G[pos][co]
@@ -235,23 +399,48 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         const int a0 = ty * p.th, b0 = tx * SSIE_TW;
         const int vy0 = a0 * p.si + p.min_dy, vx0 = b0 * p.si + p.min_dx;
         __syncthreads();
-        for (int id = tid; id < HP * CI4; id += 256) {
-            int pix = id / CI4, j = id % CI4;
-            int hy = pix / p.hp_w, hx = pix - hy * p.hp_w;
-            f32x4 v = ssie_load_virtual(s, n, vy0 + hy, vx0 + hx, p.Hv, p.Wv, ci0 + 4 * j);
-            *(f32x4*)(Xs + pix * CIB + 4 * j) = v;
-        }
-        for (int id = tid; id < PT * CO4; id += 256) {
-            int pix = id / CO4, j = id % CO4;
-            int a = a0 + pix / SSIE_TW, b = b0 + pix % SSIE_TW;
-            int c = co0 + 4 * j;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (a < p.Ho && b < p.Wo && c < p.Cout) {
-                const float* gp = p.g + ((size_t)(n * p.Ho + a) * p.Wo + b) * p.g_cstride + p.g_coff + c;
-                if (c + 3 < p.Cout) v = *(const f32x4*)gp;
-                else { v.x = gp[0]; if (c + 1 < p.Cout) v.y = gp[1]; if (c + 2 < p.Cout) v.z = gp[2]; }
+        // staging in batches of UB independent 16-byte loads per thread so the global latency is paid once per
+        // batch, not once per element
+        constexpr int UB = 6;
+        for (int base = 0; base < HP * CI4; base += 256 * UB) {
+            f32x4 r[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int id = min(base + u * 256 + tid, HP * CI4 - 1);
+                const int pix = id / CI4, j = id % CI4;
+                const int hy = pix / p.hp_w, hx = pix - hy * p.hp_w;
+                r[u] = ssie_load_virtual(s, n, vy0 + hy, vx0 + hx, p.Hv, p.Wv, ci0 + 4 * j);
             }
-            *(f32x4*)(Gs + pix * COB + 4 * j) = v;
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int id = base + u * 256 + tid;
+                if (id < HP * CI4) *(f32x4*)(Xs + (id / CI4) * CIB + 4 * (id % CI4)) = r[u];
+            }
+        }
+        for (int base = 0; base < PT * CO4; base += 256 * UB) {
+            f32x4 r[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                // branch-free: clamp the address into the tensor (g buffers are padded to a multiple of 4 channels,
+                // padding is zero), zero what lies outside the tile / channel range afterwards
+                const int id = min(base + u * 256 + tid, PT * CO4 - 1);
+                const int pix = id / CO4, j = id % CO4;
+                const int a = a0 + pix / SSIE_TW, b = b0 + pix % SSIE_TW;
+                const int c = co0 + 4 * j;
+                const bool ok = a < p.Ho && b < p.Wo && c < p.Cout;
+                const int ca = min(a, p.Ho - 1), cb = min(b, p.Wo - 1), cc = min(c, ((p.Cout + 3) & ~3) - 4);
+                f32x4 v = *(const f32x4*)(p.g + ((size_t)(n * p.Ho + ca) * p.Wo + cb) * p.g_cstride + p.g_coff + cc);
+                if (c + 1 >= p.Cout) v.y = 0.f;
+                if (c + 2 >= p.Cout) v.z = 0.f;
+                if (c + 3 >= p.Cout) v.w = 0.f;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                r[u] = ok ? v : z;
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int id = base + u * 256 + tid;
+                if (id < PT * CO4) *(f32x4*)(Gs + (id / CO4) * COB + 4 * (id % CO4)) = r[u];
+            }
         }
         __syncthreads();
         if (do_bias)
@@ -412,7 +601,24 @@ __global__ void pack_weights_batched_kernel(const PackDesc* __restrict__ descs)
 // ---------------------------------------------------------------------------------------------
 extern "C" size_t ssie_fprop_lds_bytes(const ConvParams* p, int nt)
 {
-    return (size_t)p->hp_h * p->hp_w * 64 + (size_t)SSIE_TG * 4 * 32 * nt * 16 + (size_t)p->ntaps * 4;
+    return (size_t)p->hp_h * p->hp_w * 64 + (size_t)SSIE_TG * 4 * 32 * nt * 16 + (size_t)SSIE_MAX_TAPS * 4 + 16;
+}
+
+// resident persistent workgroups per CU (tuning knob, see tools/bench_conv.py)
+int ssie_fprop_wgs_per_cu = 3;
+extern "C" void ssie_debug_set_fprop_wgs_per_cu(int v) { ssie_fprop_wgs_per_cu = v < 1 ? 1 : v; }
+
+template <int NT, int NA, int TH>
+static int launch_fprop_t(const ConvParams& p, size_t lds, hipStream_t st)
+{
+    static bool set = false;
+    if (!set) { hipFuncSetAttribute((const void*)conv_fprop_kernel<NT, NA, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    const size_t tiles = (size_t)p.N * p.tiles_y * p.tiles_x * p.co_blocks;
+    const int per_cu = (int)((160 * 1024) / lds);
+    size_t wgs = (size_t)256 * (per_cu < 1 ? 1 : (per_cu > ssie_fprop_wgs_per_cu ? ssie_fprop_wgs_per_cu : per_cu));
+    if (wgs > tiles) wgs = tiles;
+    hipLaunchKernelGGL((conv_fprop_kernel<NT, NA, TH>), dim3((unsigned)wgs), dim3(256), lds, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : 14;
 }
 
 int ssie_launch_fprop(const ConvParams& p, hipStream_t st)
@@ -422,17 +628,15 @@ int ssie_launch_fprop(const ConvParams& p, hipStream_t st)
     if (p.ntaps < 1 || p.ntaps > SSIE_MAX_TAPS) return 12;
     size_t lds = ssie_fprop_lds_bytes(&p, nt);
     if (lds > 160 * 1024) return 13;
-    dim3 grid((unsigned)((size_t)p.N * p.tiles_y * p.tiles_x * p.co_blocks));
-    if (nt == 2) {
-        static bool set2 = false;
-        if (!set2) { hipFuncSetAttribute((const void*)conv_fprop_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set2 = true; }
-        hipLaunchKernelGGL(conv_fprop_kernel<2>, grid, dim3(256), lds, st, p);
-    } else {
-        static bool set1 = false;
-        if (!set1) { hipFuncSetAttribute((const void*)conv_fprop_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set1 = true; }
-        hipLaunchKernelGGL(conv_fprop_kernel<1>, grid, dim3(256), lds, st, p);
+    const int na = (p.hp_h * p.hp_w * 4 + 255) / 256;
+    if (na > 9) return 15;
+    if (p.th == 16) {
+        if (na > 6) return 16;
+        return nt == 2 ? launch_fprop_t<2, 6, 16>(p, lds, st) : launch_fprop_t<1, 6, 16>(p, lds, st);
     }
-    return hipGetLastError() == hipSuccess ? 0 : 14;
+    if (p.th != 8) return 17;
+    if (nt == 2) return na <= 3 ? launch_fprop_t<2, 3, 8>(p, lds, st) : (na <= 6 ? launch_fprop_t<2, 6, 8>(p, lds, st) : launch_fprop_t<2, 9, 8>(p, lds, st));
+    return na <= 3 ? launch_fprop_t<1, 3, 8>(p, lds, st) : (na <= 6 ? launch_fprop_t<1, 6, 8>(p, lds, st) : launch_fprop_t<1, 9, 8>(p, lds, st));
 }
 
 template <int CI, int CO, int NU>

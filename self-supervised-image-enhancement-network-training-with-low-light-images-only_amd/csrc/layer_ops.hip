@@ -4,6 +4,9 @@
 #include "../../include/ssie_hip.h"
 #include <string.h>
 
+int ssie_fprop_tile16 = 0;   // tuning knob (tools/): 0 forces 8-row tiles everywhere
+extern "C" void ssie_debug_set_fprop_tile16(int v) { ssie_fprop_tile16 = v; }
+
 // ---------------------------------------------------------------------------------------------
 // tap lists
 // ---------------------------------------------------------------------------------------------
@@ -60,7 +63,8 @@ SrcDesc ssie_make_src(const float* ptr, int C, int cstride, int coff, int Hs, in
 size_t ssie_packed_floats(int K, int N, int T)
 {
     const int npad = N > 32 ? ssie_round_up(N, 64) : 32;
-    return (size_t)ssie_ceil_div(K, SSIE_CK) * T * 16 * npad;
+    // + one tap group of padding: the fprop kernel prefetches whole groups and may over-read a short last group
+    return (size_t)ssie_ceil_div(K, SSIE_CK) * T * 16 * npad + (size_t)(SSIE_TG + 1) * 16 * npad;
 }
 
 PackDesc ssie_make_pack(const float* w, float* dst, int K, int N, const TapList& t, int s_k, int s_n, int s_t)
@@ -91,7 +95,10 @@ int ssie_make_conv(ConvParams& p, const SrcDesc* srcs, int nsrc, int N, int Hv, 
     p.Ho = Ho; p.Wo = Wo; p.si = si; p.ntaps = t.n;
     int mny, mxy, mnx, mxx; tap_extent(t, mny, mxy, mnx, mxx);
     p.min_dy = mny; p.min_dx = mnx;
-    p.hp_h = (SSIE_TH - 1) * si + (mxy - mny) + 1;
+    // 16-row tiles for the stride-1 layers with a small halo (3x3, 1x1, parity classes): half the weight staging,
+    // barriers and tile boundaries per MFMA
+    p.th = (si == 1 && (mxy - mny) <= 2 && (mxx - mnx) <= 2 && Ho >= 16 && ssie_fprop_tile16) ? 16 : 8;
+    p.hp_h = (p.th - 1) * si + (mxy - mny) + 1;
     p.hp_w = (SSIE_TW - 1) * si + (mxx - mnx) + 1;
     for (int i = 0; i < t.n; ++i) { p.tap_dy[i] = t.dy[i]; p.tap_dx[i] = t.dx[i]; }
     p.wpacked = wpacked; p.Cout = Cout; p.Cout_pad = Cout > 32 ? ssie_round_up(Cout, 64) : 32;
@@ -99,7 +106,7 @@ int ssie_make_conv(ConvParams& p, const SrcDesc* srcs, int nsrc, int N, int Hv, 
     p.so = so; p.py = py; p.px = px;
     p.bias = e.bias; p.act = e.act; p.addsrc = e.addsrc; p.out2 = e.out2; p.mask_y = e.mask_y;
     p.mask_mode = e.mask_y ? e.mask_mode : MASK_NONE; p.accumulate = e.accumulate;
-    p.tiles_y = ssie_ceil_div(Ho, SSIE_TH); p.tiles_x = ssie_ceil_div(Wo, SSIE_TW);
+    p.tiles_y = ssie_ceil_div(Ho, p.th); p.tiles_x = ssie_ceil_div(Wo, SSIE_TW);
     p.co_blocks = p.Cout_pad > 32 ? p.Cout_pad / 64 : 1;
     return 0;
 }
@@ -165,6 +172,15 @@ static inline float* ws_take(char*& cur, char* end, size_t floats)
     float* r = (float*)cur; cur += bytes; return r;
 }
 
+// n zeroed tile-queue counters for the persistent fprop kernel
+static inline int* take_counters(char*& cur, char* end, int n, hipStream_t st)
+{
+    int* c = (int*)ws_take(cur, end, 64);
+    if (!c || n > 64) return nullptr;
+    if (hipMemsetAsync(c, 0, 256, st) != hipSuccess) return nullptr;
+    return c;
+}
+
 extern "C" int ssie_conv2d_fwd(const ssie_src_t* srcs, int nsrc, int N, int Hv, int Wv,
                                const float* weight, int cin_w, const float* bias, int cout, int k, int stride, int act,
                                const float* addsrc, float* out2, float* out, int out_cstride, int out_coff,
@@ -189,6 +205,7 @@ extern "C" int ssie_conv2d_fwd(const ssie_src_t* srcs, int nsrc, int N, int Hv, 
     ConvParams p;
     int rc = ssie_make_conv(p, sd, nsrc, N, Hv, Wv, t, stride, Ho, Wo, wp, cout, out, Ho, Wo, out_cstride, out_coff, 1, 0, 0, e);
     if (rc) return rc;
+    if (!(p.tile_counter = take_counters(cur, end, 1, st))) return SSIE_E_WORKSPACE;
     return ssie_launch_fprop(p, st) ? SSIE_E_LAUNCH : 0;
 }
 
@@ -198,6 +215,8 @@ static int transposed_like(const SrcDesc& in, int N, int Hin, int Win, int Kc, i
                            int s_k, int s_n, float* out, int Hout, int Wout, int out_cstride, int out_coff,
                            const Epilogue& e, char*& cur, char* end, hipStream_t st)
 {
+    int* counters = take_counters(cur, end, 4, st);
+    if (!counters) return SSIE_E_WORKSPACE;
     for (int py = 0; py < 2; ++py) for (int px = 0; px < 2; ++px) {
         TapList t = ssie_taps_transposed(3, 1, py, px);
         float* wp = ws_take(cur, end, ssie_packed_floats(Kc, Nc, t.n));
@@ -208,6 +227,7 @@ static int transposed_like(const SrcDesc& in, int N, int Hin, int Win, int Kc, i
         const int Ho = ssie_ceil_div(Hout - py, 2), Wo = ssie_ceil_div(Wout - px, 2);
         int rc = ssie_make_conv(p, &in, 1, N, Hin, Win, t, 1, Ho, Wo, wp, Nc, out, Hout, Wout, out_cstride, out_coff, 2, py, px, e);
         if (rc) return rc;
+        p.tile_counter = counters + py * 2 + px;
         if (ssie_launch_fprop(p, st)) return SSIE_E_LAUNCH;
     }
     return 0;
@@ -250,6 +270,7 @@ extern "C" int ssie_conv2d_dgrad(const float* g, int g_cstride, int g_coff, int 
         ConvParams p;
         int rc = ssie_make_conv(p, &in, 1, N, Ho, Wo, t, 1, Hin, Win, wp, cs, gx, Hin, Win, gx_cstride, gx_coff, 1, 0, 0, e);
         if (rc) return rc;
+        if (!(p.tile_counter = take_counters(cur, end, 1, st))) return SSIE_E_WORKSPACE;
         return ssie_launch_fprop(p, st) ? SSIE_E_LAUNCH : 0;
     }
     return transposed_like(in, N, Ho, Wo, cout, cs, wbase, cin_total * T, T, gx, Hin, Win, gx_cstride, gx_coff, e, cur, end, st);
@@ -275,6 +296,7 @@ extern "C" int ssie_conv_transpose2d_dgrad(const float* g, int g_cstride, int g_
     ConvParams p;
     int rc = ssie_make_conv(p, &in, 1, N, 2 * Hin, 2 * Win, t, 2, Hin, Win, wp, cin, gx, Hin, Win, gx_cstride, gx_coff, 1, 0, 0, e);
     if (rc) return rc;
+    if (!(p.tile_counter = take_counters(cur, end, 1, st))) return SSIE_E_WORKSPACE;
     return ssie_launch_fprop(p, st) ? SSIE_E_LAUNCH : 0;
 }
 

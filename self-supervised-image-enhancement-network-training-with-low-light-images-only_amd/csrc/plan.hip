@@ -44,7 +44,8 @@ struct Plan {
     std::map<std::string, BufInfo> bufs;
     size_t ws_floats = 0;
     size_t slab_off = 0, slab_cap = 0, partial_off = 0, packdesc_off = 0, mask_off = 0, scal_off = 0;
-    size_t lpart_off = 0, fpart_off = 0;
+    size_t lpart_off = 0, fpart_off = 0, counter_off = 0;
+    int counter_cursor = 0;
     int loss_blocks = 0, fft_blocks = 0;
     float coefs[8];
     // bound state
@@ -147,6 +148,7 @@ void build_buffers(Plan& pl)
     pl.fpart_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + (size_t)pl.fft_blocks, 64);
     pl.scal_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 16, 64);
     pl.mask_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + ((size_t)H * W + 3) / 4, 64);
+    pl.counter_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 1024, 64);      // tile-queue counters, one per conv launch
     pl.packdesc_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 256 * sizeof(PackDesc) / 4, 64);
     pl.pack_off = pl.ws_floats;     // packed weights grow from here at bind time (size known after a dry build)
 }
@@ -155,7 +157,7 @@ void build_buffers(Plan& pl)
 struct Builder {
     Plan& pl;
     bool dry;                 // dry run: only count packed-weight floats
-    explicit Builder(Plan& p, bool d) : pl(p), dry(d) { pl.pack_cursor = 0; pl.packs.clear(); }
+    explicit Builder(Plan& p, bool d) : pl(p), dry(d) { pl.pack_cursor = 0; pl.packs.clear(); pl.counter_cursor = 0; }
 
     float* take_pack(size_t floats)
     {
@@ -171,9 +173,10 @@ struct Builder {
     float* ptr(const char* name) { return dry ? nullptr : pl.buf(name); }
     float* par(size_t off) { return dry ? nullptr : pl.P + off; }
     float* grad(size_t off) { return dry ? nullptr : pl.G + off; }
-    void push(std::vector<Fn>& ops, const ConvParams& p, int k_real)
+    void push(std::vector<Fn>& ops, ConvParams p, int k_real)
     {
         if (dry) return;
+        if (pl.counter_cursor < 1024) p.tile_counter = (int*)(pl.ws + pl.counter_off) + pl.counter_cursor++;
         // algorithmic FLOPs: real (un-padded) channels and taps only
         const double fl = 2.0 * p.N * p.Ho * p.Wo * (double)p.Cout * k_real * p.ntaps;
         ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_fprop(p, st); }, p.Cout_pad % 64 == 0 ? K_FPROP2 : K_FPROP1, fl));
@@ -629,6 +632,8 @@ extern "C" int ssie_plan_bind(void* h, void* workspace, size_t ws_bytes, float* 
 
 static int pack_all(Plan* pl, hipStream_t st)
 {
+    // tile-queue counters of every conv launch of this step (one memset node)
+    if (hipMemsetAsync(pl->ws + pl->counter_off, 0, 1024 * 4, st) != hipSuccess) return SSIE_E_LAUNCH;
     return ssie_launch_pack_batched((const PackDesc*)(pl->ws + pl->packdesc_off), (int)pl->packs.size(), st) ? SSIE_E_LAUNCH : 0;
 }
 

@@ -60,6 +60,8 @@ struct ConvParams {
     int mask_mode;
     int accumulate;         // out += v instead of out = v
     int tiles_y, tiles_x, co_blocks;
+    int th;                 // output tile rows: 8, or 16 for the stride-1 3x3 / 1x1 layers
+    int* tile_counter;      // optional dynamic tile queue (device int, zero before the launch); null = static stride
 };
 
 struct WgradParams {

@@ -17,12 +17,18 @@ def timeit(fn, iters=10):
 
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    only = sys.argv[2] if len(sys.argv) > 2 else None
+    iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
     dev = "cuda"
     L = H.lib()
+    if os.environ.get('SSIE_WGS'):
+        L.ssie_debug_set_fprop_wgs_per_cu(int(os.environ['SSIE_WGS']))
     for (name, cin, cout, k, stride, hw) in [("conv1 64->64 3x3", 64, 64, 3, 1, 128), ("shallow 32->64 9x9", 32, 64, 9, 1, 128),
                                               ("conv0 32->32 3x3", 32, 32, 3, 1, 128), ("conv3 128->128 @64", 128, 128, 3, 1, 64),
                                               ("conv2 64->128 s2", 64, 128, 3, 2, 128), ("conv5 128->64", 128, 64, 3, 1, 128),
                                               ("fusion 192->64 1x1", 192, 64, 1, 1, 128)]:
+        if only and not name.startswith(only):
+            continue
         x = torch.randn(N, hw, hw, cin, device=dev)
         w = torch.randn(cout, cin, k, k, device=dev) * 0.05
         b = torch.randn(cout, device=dev)
@@ -39,7 +45,7 @@ def main():
         f = lambda: H.check(L.ssie_conv2d_fwd(arr, 1, N, hw, hw, H.ptr(w), cin, H.ptr(b), cout, k, stride, 1, None, None, H.ptr(out), cout, 0, H.ptr(ws), wsb, H.stream_ptr()), "fwd")
         d = lambda: H.check(L.ssie_conv2d_dgrad(H.ptr(g), cout, 0, N, ho, ho, cout, H.ptr(w), cin, 0, cin, k, stride, H.ptr(gx), hw, hw, cin, 0, None, 0, 0, H.ptr(ws), wsb, H.stream_ptr()), "dgrad")
         wg = lambda: H.check(L.ssie_conv2d_wgrad(C.byref(src), N, hw, hw, H.ptr(g), cout, 0, cout, k, stride, cin, 0, H.ptr(dw), H.ptr(db), 0, H.ptr(ws), wsb, H.stream_ptr()), "wgrad")
-        tf, td, tw = timeit(f), timeit(d), timeit(wg)
+        tf, td, tw = timeit(f, iters), timeit(d, iters), timeit(wg, iters)
         print(f"{name:22s} N={N} fprop {tf*1e6:8.1f} us {flops/tf/1e12:6.1f} TF | dgrad {td*1e6:8.1f} us {flops/td/1e12:6.1f} TF | wgrad {tw*1e6:8.1f} us {flops/tw/1e12:6.1f} TF", flush=True)
 
 if __name__ == "__main__":
