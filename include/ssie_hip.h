@@ -93,6 +93,12 @@ int ssie_attention_fwd(const float* qkv, float* out, float* lse, int N, int T, v
 int ssie_attention_bwd(const float* qkv, const float* out, const float* gout, const float* lse,
                        float* delta_ws, float* gqkv, int N, int T, void* stream);
 
+/* device-side batch assembly = the host loop of model.py:301-310 + utils.data_augmentation (utils.py:7-34):
+ * crops_dev = n records {const float* cube (H,W,C fp32 on device); int H, W, x0 (row), y0 (col), mode 0..7};
+ * out = (n, P, P, cs) NHWC patches, channels >= C zero-padded */
+int ssie_assemble_batch(const void* crops_dev, int n, float* out, int P, int C, int cs, void* stream);
+int ssie_aug_source_index(int mode, int P, int i, int j, int* si, int* sj);   /* host: index map of the 8 augmentations */
+
 /* ---- plan executor: the whole hot path as a static launch schedule -----------------------------
  * coefs8 = {c_loss_reconstruction, c_loss_r_fidelity, c_loss_i_smooth_low, c_loss_i_smooth_delta,
  *           c_loss_fourier, c_loss_spectral_cons, alpha_i_smooth_low, alpha_i_smooth_delta}

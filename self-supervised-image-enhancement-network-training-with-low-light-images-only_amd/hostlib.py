@@ -310,3 +310,25 @@ def attention_bwd(qkv, out, gout, lse):
     check(lib().ssie_attention_bwd(ptr(qkv), ptr(out), ptr(gout), ptr(lse), ptr(delta), ptr(gqkv), n, t, stream_ptr()),
           "ssie_attention_bwd")
     return gqkv
+
+
+class CropT(C.Structure):
+    _fields_ = [("cube", C.c_void_p), ("H", C.c_int), ("W", C.c_int), ("x0", C.c_int), ("y0", C.c_int), ("mode", C.c_int)]
+
+
+def assemble_batch(cubes, crops, patch: int, bands: int) -> torch.Tensor:
+    """cubes: list of (H,W,C) fp32 cuda tensors; crops: [(cube index, x0, y0, mode)] -> logical (n, C, P, P) channels_last batch"""
+    import numpy as np
+    n = len(crops)
+    dev = cubes[0].device
+    recs = (CropT * n)()
+    for i, (ci, x0, y0, mode) in enumerate(crops):
+        cb = cubes[ci]
+        assert cb.is_contiguous() and cb.dtype == torch.float32 and cb.shape[2] == bands
+        assert 0 <= x0 <= cb.shape[0] - patch and 0 <= y0 <= cb.shape[1] - patch and 0 <= mode < 8
+        recs[i] = CropT(cb.data_ptr(), cb.shape[0], cb.shape[1], x0, y0, mode)
+    raw = torch.frombuffer(bytearray(bytes(recs)), dtype=torch.uint8).to(dev)
+    cs = (bands + 3) // 4 * 4
+    out = torch.empty(n, patch, patch, cs, device=dev)
+    check(lib().ssie_assemble_batch(ptr(raw), n, ptr(out), patch, bands, cs, stream_ptr()), "ssie_assemble_batch")
+    return out[..., :bands].permute(0, 3, 1, 2)

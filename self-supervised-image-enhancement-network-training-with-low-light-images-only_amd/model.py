@@ -19,6 +19,7 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 
+from . import dp
 from . import hostlib as H
 
 LOSS_KEYS = H.LOSS_KEYS
@@ -236,13 +237,12 @@ class LowLightEnhance(nn.Module):
         x = self._f32(input_low)
         plan = self._plan_for(x)
         plan.loss_fwd_bwd(x, backward=True)
-        if world_size > 1:
-            torch.distributed.all_reduce(self._gflat)          # one flat fp32 buffer over RCCL / xGMI
+        gscale = dp.allreduce_flat_(self._gflat, world_size)   # one flat fp32 buffer over RCCL / xGMI
         opt = self.optimizer
         m, v = opt._buffers()
         g = opt.param_groups[0]
         opt.step_count += 1
-        H.adam_step(self._flat, self._gflat, m, v, opt.step_count, float(g["lr"]), 1.0 / world_size,
+        H.adam_step(self._flat, self._gflat, m, v, opt.step_count, float(g["lr"]), gscale,
                     g["betas"][0], g["betas"][1], g["eps"])
         return plan.loss_scalars()
 

@@ -1,0 +1,104 @@
+"""CPU: data-parallel host logic over gloo (world_size 2) and the augmentation index map.
+
+The HIP kernels cannot run here, so per-rank gradients come from the CPU oracle (test infrastructure); what is
+under test is the product's DP logic (`ssie_amd.dp`): sharding, the single flat all-reduce, the 1/world scale —
+"k-rank averaged gradients == 1-rank gradients on the concatenated batch" (SURVEY §8(e)), rel-L2 <= 1e-5.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import ssie_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, bands, hw, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    import ssie
+    ssie.load()
+    from ssie_amd import dp, hostlib as H
+    r, w, _ = dp.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    table, total = H.param_table(bands)
+    P = O.closed_form_params(bands)
+    x = O.synthetic_patches(4, bands, hw, hw)                     # global batch 4
+    mine = dp.shard_range(4, rank, world)
+    xs = x[mine.start:mine.stop]
+    _, grads, _ = O.loss_and_grads(P, xs, O.JYU_COEFS)
+    flat = torch.zeros(total)
+    for name, off, shape in table:
+        flat[off:off + grads[name].numel()] = grads[name].reshape(-1)
+    scale = dp.allreduce_flat_(flat, world)
+    flat *= scale
+    if rank == 0:
+        torch.save(flat, os.path.join(out_dir, "dp_flat.pt"))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_dp_two_ranks_equal_single_rank_on_concatenated_batch(tmp_path):
+    bands, hw = 5, 16
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, bands, hw, str(tmp_path)), nprocs=2, join=True)
+    flat = torch.load(os.path.join(tmp_path, "dp_flat.pt"), weights_only=True)
+    import ssie
+    ssie.load()
+    from ssie_amd import hostlib as H
+    table, total = H.param_table(bands)
+    P = O.closed_form_params(bands)
+    x = O.synthetic_patches(4, bands, hw, hw)
+    _, grads, _ = O.loss_and_grads({k: v.double() for k, v in P.items()}, x.double(), O.JYU_COEFS)
+    _, g32, _ = O.loss_and_grads(P, x, O.JYU_COEFS)
+    for name, off, shape in table:
+        if name.endswith("k_linear.bias"):
+            continue
+        got = flat[off:off + int(np.prod(shape))].double()
+        ref = grads[name].reshape(-1)
+        # NOTE the Fourier / smoothness means are per-batch means of |.|: the rank average of shard gradients equals the
+        # gradient of the global mean exactly in exact arithmetic; fp32 sign flips bound the agreement (see test_plan_gpu)
+        tol = max(1e-5, 2.0 * (g32[name].reshape(-1).double() - ref).norm().item() / max(ref.norm().item(), 1e-30))
+        assert (got - ref).norm().item() <= tol * ref.norm().item() + 1e-12, (name, tol)
+
+
+def test_shard_range_and_errors():
+    import ssie
+    ssie.load()
+    from ssie_amd import dp
+    assert list(dp.shard_range(8, 1, 4)) == [2, 3]
+    assert [i for r in range(8) for i in dp.shard_range(256, r, 8)] == list(range(256))
+    with pytest.raises(ValueError):
+        dp.shard_range(10, 0, 4)
+    assert dp.rank_seed(41, 3) == 44
+
+
+def test_augmentation_index_map_matches_reference(golden_dir):
+    """ssie_aug_source_index (the map the device kernel uses) vs reference crops+augmentations (aux.npz fixtures)."""
+    import ctypes
+    import ssie
+    ssie.load()
+    from ssie_amd import hostlib as H
+    L = H.lib()
+    g = np.load(os.path.join(golden_dir, "aux.npz"))
+    cube = g["aug_cube"]
+    P = 16
+    for (x0, y0, mode) in g["aug_crops"]:
+        ref = g["aug_patch_%d" % mode]
+        out = np.zeros_like(ref)
+        si = ctypes.c_int(); sj = ctypes.c_int()
+        for i in range(P):
+            for j in range(P):
+                assert L.ssie_aug_source_index(int(mode), P, i, j, ctypes.byref(si), ctypes.byref(sj)) == 0
+                out[i, j] = cube[x0 + si.value, y0 + sj.value]
+        assert np.array_equal(out, ref), mode
