@@ -141,6 +141,10 @@ int ssie_plan_loss_fwd_bwd(void* plan, const float* x, const long* strides4, int
 int ssie_plan_profile_step(void* plan, const float* x, const long* strides4, void* stream,
                            double* ms, double* flops, int* counts);
 
+/* dev tool: per-launch device ms / algorithmic FLOPs / kind in launch order; returns the op count (or -error) */
+int ssie_plan_profile_ops(void* plan, const float* x, const long* strides4, void* stream,
+                          double* ms, double* flops, int* kinds, int cap, char* tags, int tags_cap);
+
 /* torch.optim.Adam.step with default hyper-parameters (model.py:213, :316) over flat buffers;
  * grads are multiplied by grad_scale first (1/world_size after an all-reduce-sum) */
 int ssie_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n,

@@ -1,0 +1,287 @@
+// conv_fprop_v2_kernel: the stride-1 implicit-GEMM convolution (forward + data gradient) restructured for ONE
+// 512-thread workgroup per CU:
+//   * 16 x 16 output positions x 64 (or 32) channels per tile; 8 waves = 4 (M) x 2 (N), two waves per SIMD
+//   * LDS is DOUBLE-buffered and filled by direct global->LDS DMA (global_load_lds_dwordx4): no staging VGPRs, no
+//     ds_write pass, and exactly ONE barrier per step - the loads of step s+1 are issued right after the barrier of
+//     step s and have the whole MFMA phase of step s to land
+//   * the halo tile's 16-byte slot swizzle moves to the per-lane SOURCE address (the DMA writes LDS linearly:
+//     wave-uniform base + lane*16); out-of-image / out-of-channel slots read a zero page in global memory
+//   * persistent workgroups + dynamic tile queue + cross-tile prefetch exactly as in the v1 kernel
+// Same math, same packed-weight layout, same epilogue as conv_fprop_kernel (conv_kernels.hip).
+#include "conv_device.h"
+
+__device__ f32x4 ssie_zero_page[4];   // zero-initialised: source of padding slots
+
+#define GLDS16(gptr, lptr)                                                                             \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),            \
+                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+// source address of 4 consecutive channels of virtual pixel (n, vy, vx), or the zero page.  `up` (wave-uniform)
+// selects the nearest-up-sampling path; plain sources take a handful of 32-bit integer ops.
+__device__ __forceinline__ const f32x4* ssie_virtual_addr(const SrcSel& s, bool up, int n, int vy, int vx, int Hv, int Wv, int c)
+{
+    const bool ok = (unsigned)vy < (unsigned)Hv && (unsigned)vx < (unsigned)Wv && c < s.C;
+    int y = vy, x = vx;
+    if (up) {
+        const int cy = min(max(vy, 0), Hv - 1), cx = min(max(vx, 0), Wv - 1);
+        y = min((int)floorf((float)cy * s.sy), s.Hs - 1);
+        x = min((int)floorf((float)cx * s.sx), s.Ws - 1);
+    }
+    const unsigned off = (unsigned)((n * s.Hs + y) * s.Ws + x) * (unsigned)s.cstride + (unsigned)(s.coff + c);
+    return ok ? (const f32x4*)(s.ptr + off) : (const f32x4*)ssie_zero_page;
+}
+
+template <int NT, int NA2>
+__global__ __launch_bounds__(512, 2) void conv_fprop_v2_kernel(const ConvParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    constexpr int BN = 32 * NT, TH = 16;
+    constexpr int MT = (NT == 1) ? 1 : 2;
+    constexpr int BSZ = SSIE_TG * 4 * BN;           // float4 per B buffer
+    const int HP = p.hp_h * p.hp_w, HP4 = HP * 4;
+    f32x4* As0 = (f32x4*)smem_f;                    // [2][HP4]
+    f32x4* Bs0 = As0 + 2 * HP4;                     // [2][BSZ]
+    int* tapoff = (int*)(Bs0 + 2 * BSZ);
+    int* s_next = tapoff + SSIE_MAX_TAPS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, li = lane & 31;
+    const int wn = (NT == 1) ? 0 : (wave & 1);
+    const int wm = (NT == 1) ? wave : (wave >> 1);
+
+    for (int t = tid; t < p.ntaps; t += 512)
+        tapoff[t] = ((int)p.tap_dy[t] - p.min_dy) * p.hp_w + ((int)p.tap_dx[t] - p.min_dx);
+
+    int pixbase[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int mt = wm * MT + m;
+        pixbase[m] = (2 * mt + (li >> 4)) * p.hp_w + (li & 15);
+    }
+    const int ngroups = (p.ntaps + SSIE_TG - 1) / SSIE_TG;
+    const int nsteps = p.nchunks * ngroups;
+    const int total_tiles = p.N * p.tiles_y * p.tiles_x * p.co_blocks;
+
+    // this lane's halo slots: LDS slot id = i*512 + tid (linear), it holds channel quad j = (id&3) ^ swz(pixel)
+    int ahy[NA2], ahx[NA2], aj[NA2];
+#pragma unroll
+    for (int i = 0; i < NA2; ++i) {
+        const int id = min(tid + i * 512, HP4 - 1);
+        const int pix = id >> 2;
+        ahy[i] = pix / p.hp_w; ahx[i] = pix - ahy[i] * p.hp_w; aj[i] = (id & 3) ^ ssie_swz(pix);
+    }
+
+#define V2_DECODE(T, N_, A0_, B0_, CO0_)                                                  \
+    {                                                                                     \
+        int q_ = (T);                                                                     \
+        CO0_ = (q_ % p.co_blocks) * BN; q_ /= p.co_blocks;                                \
+        B0_ = (q_ % p.tiles_x) * SSIE_TW; q_ /= p.tiles_x;                                \
+        A0_ = (q_ % p.tiles_y) * TH; N_ = q_ / p.tiles_y;                                 \
+    }
+    // DMA the operands of step (CHUNK, G) of tile (N_, A0_, B0_, CO0_): weights into B buffer BUF, and (first tap group
+    // of a chunk only) the halo tile into A buffer ABUF
+#define V2_PREFETCH(CHUNK, G, N_, A0_, B0_, CO0_, BUF, ABUF)                                                        \
+    {                                                                                                         \
+        if ((G) == 0) {                                                                                       \
+            const SrcSel s_ = ssie_pick_src(p, (CHUNK) * SSIE_CK);                                            \
+            const bool up_ = s_.sy != 1.f || s_.sx != 1.f;                                                    \
+            const int vy0_ = (A0_) + p.min_dy, vx0_ = (B0_) + p.min_dx;                                       \
+            f32x4* abuf_ = As0 + (ABUF) * HP4;                                                                \
+            _Pragma("unroll") for (int i_ = 0; i_ < NA2; ++i_) {                                              \
+                if (tid + i_ * 512 < HP4) {                                                                   \
+                    const f32x4* g_ = ssie_virtual_addr(s_, up_, (N_), vy0_ + ahy[i_], vx0_ + ahx[i_], p.Hv, p.Wv, \
+                                                        (CHUNK) * SSIE_CK + 4 * aj[i_] - s_.cbeg);            \
+                    GLDS16(g_, abuf_ + i_ * 512 + wave * 64);                                                 \
+                }                                                                                             \
+            }                                                                                                 \
+        }                                                                                                     \
+        const int t0_ = (G) * SSIE_TG;                                                                        \
+        const int pieces_ = min(SSIE_TG, p.ntaps - t0_) * 4 * BN / 64;                                        \
+        const f32x4* wsrc_ = (const f32x4*)p.wpacked + ((size_t)((CHUNK) * p.ntaps + t0_) * 4) * p.Cout_pad + (CO0_); \
+        f32x4* bbuf_ = Bs0 + (BUF) * BSZ;                                                                     \
+        for (int q_ = wave; q_ < pieces_; q_ += 8) {                                                          \
+            const int slot_ = q_ * 64 + lane;                                                                 \
+            GLDS16(wsrc_ + (size_t)(slot_ / BN) * p.Cout_pad + (slot_ % BN), bbuf_ + q_ * 64);                \
+        }                                                                                                     \
+    }
+
+    int tile = blockIdx.x;
+    if (tile >= total_tiles) return;
+    int n, a0, b0, co0;
+    V2_DECODE(tile, n, a0, b0, co0)
+    int gstep = 0;
+    int a_cur = 0;          // A buffer holding the halo tile of the step about to be computed
+    V2_PREFETCH(0, 0, n, a0, b0, co0, 0, 0)
+    int fetched = 0x7fffffff;
+    // The two waves of a SIMD (w and w+4) run the same program; issuing the next step's DMA (address VALU work) at
+    // the same moment would leave the SIMD's MFMA pipe idle.  Waves 4-7 therefore issue it in the middle of their
+    // tap loop while waves 0-3 issue it up front.
+    const bool late_prefetch = false;   // measured: issuing the DMA inside the tap loop (waves 4-7) was 5-25 % SLOWER
+
+    while (tile < total_tiles) {
+        f32x16 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        int ntile = 0x7fffffff;
+        int nn = n, na0 = a0, nb0 = b0, nco0 = co0;
+
+        int chunk = 0, g = 0;
+        for (int step = 0; step < nsteps; ++step, ++gstep) {
+            const int buf = gstep & 1;
+            const int t0 = g * SSIE_TG;
+            const int tg = min(SSIE_TG, p.ntaps - t0);
+            // dynamic tile queue: the counter is drawn one step ahead and handed over through LDS across this barrier
+            if (tid == 0) {
+                if (nsteps == 1 || !p.tile_counter) {
+                    if (step == 0) *s_next = p.tile_counter ? (int)gridDim.x + atomicAdd(p.tile_counter, 1) : tile + (int)gridDim.x;
+                } else if (step == 1) *s_next = fetched;
+            }
+            // ONE barrier per step: my DMA for this step has landed (vmcnt) and every wave has finished reading the
+            // other buffer (previous step), which the prefetch below overwrites
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (step == (nsteps > 1 ? 1 : 0)) {
+                ntile = *s_next;
+                if (ntile < total_tiles) V2_DECODE(ntile, nn, na0, nb0, nco0)
+            }
+            int nchunk = chunk, ng = g + 1;
+            if (ng == ngroups) { ng = 0; ++nchunk; }
+            const bool more = step + 1 < nsteps;
+            const int a_nxt = ((more ? ng : 0) == 0) ? (a_cur ^ 1) : a_cur;     // a new halo tile goes to the other A buffer
+#define V2_ISSUE_NEXT                                                                                     \
+            {                                                                                             \
+                if (more) V2_PREFETCH(nchunk, ng, n, a0, b0, co0, buf ^ 1, a_nxt)                         \
+                else if (ntile < total_tiles) V2_PREFETCH(0, 0, nn, na0, nb0, nco0, buf ^ 1, a_nxt)       \
+            }
+            if (!late_prefetch) V2_ISSUE_NEXT
+
+            const f32x4* As = As0 + a_cur * HP4;
+            const f32x4* Bs = Bs0 + buf * BSZ;
+#define V2_LDFRAG(BF, AF, TL, KQ, OFF)                                                                \
+            {                                                                                             \
+                BF = Bs[((TL) * 4 + (KQ) * 2 + h) * BN + wn * 32 + li];                                   \
+                _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_) {                                       \
+                    const int hp_ = pixbase[m_] + (OFF);                                                  \
+                    AF[m_] = As[hp_ * 4 + (((KQ) * 2 + h) ^ ssie_swz(hp_))];                              \
+                }                                                                                         \
+            }
+#define V2_MFMA4(BF, AF)                                                                              \
+            _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_) {                                           \
+                acc[m_] = MFMA32(AF[m_].x, BF.x, acc[m_]); acc[m_] = MFMA32(AF[m_].y, BF.y, acc[m_]);     \
+                acc[m_] = MFMA32(AF[m_].z, BF.z, acc[m_]); acc[m_] = MFMA32(AF[m_].w, BF.w, acc[m_]);     \
+            }
+            {
+                f32x4 bX, bY, aX[MT], aY[MT];
+                int off = tapoff[t0];
+                V2_LDFRAG(bX, aX, 0, 0, off)
+                const int pf_at = late_prefetch ? (tg >> 1) : -1;
+                for (int tl = 0; tl < tg; ++tl) {
+                    const int off_next = tapoff[t0 + min(tl + 1, tg - 1)];
+                    V2_LDFRAG(bY, aY, tl, 1, off)
+                    V2_MFMA4(bX, aX)
+                    if (tl == pf_at) V2_ISSUE_NEXT
+                    if (tl + 1 < tg) V2_LDFRAG(bX, aX, tl + 1, 0, off_next)
+                    V2_MFMA4(bY, aY)
+                    off = off_next;
+                }
+            }
+#undef V2_LDFRAG
+#undef V2_MFMA4
+#undef V2_ISSUE_NEXT
+            // draw the tile after next from the queue; its value is only needed at the next step's hand-off
+            if (tid == 0 && step == 0 && nsteps > 1 && p.tile_counter)
+                fetched = (int)gridDim.x + atomicAdd(p.tile_counter, 1);
+            chunk = nchunk; g = ng; a_cur = a_nxt;
+        }
+
+        // epilogue (identical mapping to the v1 kernel; TH = 16 so M-tile mt covers tile rows 2*mt, 2*mt+1)
+        const int co = co0 + wn * 32 + li;
+        if (co < p.Cout) {
+            const float bv = p.bias ? p.bias[co] : 0.f;
+            const long rowstride = (long)p.so * p.Wout * p.out_cstride;
+            const long pixstride = (long)p.so * p.out_cstride;
+            const bool simple = p.mask_mode == MASK_NONE && !p.out2 && !p.addsrc && !p.accumulate;
+            const bool full = a0 + TH <= p.Ho && b0 + SSIE_TW <= p.Wo &&
+                              (a0 + TH - 1) * p.so + p.py < p.Hout && (b0 + SSIE_TW - 1) * p.so + p.px < p.Wout;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int mt = wm * MT + m;
+                const int arow = a0 + 2 * mt, bcol = b0 + 4 * h;
+                const size_t o0 = ((size_t)(n * p.Hout + arow * p.so + p.py) * p.Wout + bcol * p.so + p.px) * p.out_cstride + p.out_coff + co;
+                if (simple && full) {
+                    float* ob = p.out + o0;
+                    if (p.act == ACT_RELU) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) ob[(r >> 3) * rowstride + ((r & 3) + 8 * ((r >> 2) & 1)) * pixstride] = fmaxf(acc[m][r] + bv, 0.f);
+                    } else if (p.act == ACT_NONE) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) ob[(r >> 3) * rowstride + ((r & 3) + 8 * ((r >> 2) & 1)) * pixstride] = acc[m][r] + bv;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) ob[(r >> 3) * rowstride + ((r & 3) + 8 * ((r >> 2) & 1)) * pixstride] = 1.f / (1.f + expf(-(acc[m][r] + bv)));
+                    }
+                    continue;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int tr = r >> 3, tc = (r & 3) + 8 * ((r >> 2) & 1);
+                    const int a = arow + tr, b = bcol + tc;
+                    if (a >= p.Ho || b >= p.Wo) continue;
+                    if (a * p.so + p.py >= p.Hout || b * p.so + p.px >= p.Wout) continue;
+                    const size_t o = o0 + tr * rowstride + tc * pixstride;
+                    float v = acc[m][r] + bv;
+                    if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (p.act == ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+                    if (p.mask_mode == MASK_RELU) v = p.mask_y[o] > 0.f ? v : 0.f;
+                    else if (p.mask_mode == MASK_SIGMOID) { float y = p.mask_y[o]; v *= y * (1.f - y); }
+                    if (p.out2) p.out2[o] = v;
+                    if (p.addsrc) v += p.addsrc[o];
+                    if (p.accumulate) v += p.out[o];
+                    p.out[o] = v;
+                }
+            }
+        }
+        n = nn; a0 = na0; b0 = nb0; co0 = nco0; tile = ntile;
+    }
+#undef V2_PREFETCH
+#undef V2_DECODE
+}
+
+#define INST_V2(NT, NA2) template __global__ void conv_fprop_v2_kernel<NT, NA2>(const ConvParams);
+INST_V2(1, 3) INST_V2(1, 5) INST_V2(2, 3) INST_V2(2, 5)
+
+size_t ssie_fprop_v2_lds_bytes(const ConvParams& p, int nt)
+{
+    return 2 * ((size_t)p.hp_h * p.hp_w * 64 + (size_t)SSIE_TG * 4 * 32 * nt * 16) + (size_t)SSIE_MAX_TAPS * 4 + 16;
+}
+
+// eligible: stride-1 geometry built with th == 16 whose double-buffered tiles fit the 160 KiB LDS
+bool ssie_fprop_v2_ok(const ConvParams& p)
+{
+    if (p.th != 16 || p.si != 1) return false;
+    const int nt = (p.Cout_pad % 64 == 0) ? 2 : 1;
+    const int na2 = (p.hp_h * p.hp_w * 4 + 511) / 512;
+    return na2 <= 5 && ssie_fprop_v2_lds_bytes(p, nt) <= 160 * 1024;
+}
+
+template <int NT, int NA2>
+static int launch_v2_t(const ConvParams& p, size_t lds, hipStream_t st)
+{
+    static bool set = false;
+    if (!set) { hipFuncSetAttribute((const void*)conv_fprop_v2_kernel<NT, NA2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    const size_t tiles = (size_t)p.N * p.tiles_y * p.tiles_x * p.co_blocks;
+    const size_t wgs = tiles < 256 ? tiles : 256;
+    hipLaunchKernelGGL((conv_fprop_v2_kernel<NT, NA2>), dim3((unsigned)wgs), dim3(512), lds, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : 18;
+}
+
+int ssie_launch_fprop_v2(const ConvParams& p, hipStream_t st)
+{
+    const int nt = (p.Cout_pad % 64 == 0) ? 2 : 1;
+    const int na2 = (p.hp_h * p.hp_w * 4 + 511) / 512;
+    const size_t lds = ssie_fprop_v2_lds_bytes(p, nt);
+    if (nt == 2) return na2 <= 3 ? launch_v2_t<2, 3>(p, lds, st) : launch_v2_t<2, 5>(p, lds, st);
+    return na2 <= 3 ? launch_v2_t<1, 3>(p, lds, st) : launch_v2_t<1, 5>(p, lds, st);
+}

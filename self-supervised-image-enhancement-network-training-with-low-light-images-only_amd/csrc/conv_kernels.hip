@@ -13,9 +13,7 @@
 // 16-channel chunk in LDS and re-read by all taps (LDS-staged 3x3 / 9x9 tiles); weights are
 // staged per tap group.  K is permuted inside each chunk so that one ds_read_b128 feeds four
 // consecutive MFMAs: lane (i, h) holds channels 8*kq + 4*h + {0..3}.
-#include "ssie_common.h"
-
-#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#include "conv_device.h"
 
 // Diagnostic build only (-DSSIE_STAMP, tools/stamp_conv.py): per-workgroup s_memtime stamps of the fprop phases,
 // written to a buffer of their own.  The shipped library never executes a stamp.
@@ -39,52 +37,6 @@ extern "C" int ssie_debug_set_stamp_buffer(void* buf)
 #define STAMP_ACC(var)
 #define STAMP_FLUSH
 #endif
-
-__device__ __forceinline__ int ssie_swz(int hp) { return (hp >> 2) & 3; }
-
-struct SrcSel {
-    const float* ptr; int C, cstride, coff, Hs, Ws; float sy, sx; int cbeg;
-};
-
-// Picking the source of a chunk must not index the by-value kernarg struct at run time (hipcc then spills
-// the whole 470-byte struct to scratch) and must not select between loads either (instcombine folds that
-// back into a load of a selected ADDRESS).  So the three descriptors are blended arithmetically:
-// v = v0 + m1*(v1-v0) + m2*(v2-v1), m1 = [which >= 1], m2 = [which == 2] - a few scalar integer ops per chunk.
-template <typename PT>
-__device__ __forceinline__ SrcSel ssie_pick_src(const PT& p, int c_first)
-{
-    const int c1 = p.src[0].C, c2 = p.src[0].C + p.src[1].C;
-    const int m1 = (p.nsrc > 1 && c_first >= c1) ? 1 : 0;
-    const int m2 = (p.nsrc > 2 && c_first >= c2) ? 1 : 0;
-    auto bl = [&](int v0, int v1, int v2) { return v0 + m1 * (v1 - v0) + m2 * (v2 - v1); };
-    SrcSel r;
-    const long long q0 = (long long)p.src[0].ptr, q1 = (long long)p.src[1].ptr, q2 = (long long)p.src[2].ptr;
-    r.ptr = (const float*)(q0 + m1 * (q1 - q0) + m2 * (q2 - q1));
-    r.C = bl(p.src[0].C, p.src[1].C, p.src[2].C);
-    r.cstride = bl(p.src[0].cstride, p.src[1].cstride, p.src[2].cstride);
-    r.coff = bl(p.src[0].coff, p.src[1].coff, p.src[2].coff);
-    r.Hs = bl(p.src[0].Hs, p.src[1].Hs, p.src[2].Hs);
-    r.Ws = bl(p.src[0].Ws, p.src[1].Ws, p.src[2].Ws);
-    r.sy = __int_as_float(bl(__float_as_int(p.src[0].sy), __float_as_int(p.src[1].sy), __float_as_int(p.src[2].sy)));
-    r.sx = __int_as_float(bl(__float_as_int(p.src[0].sx), __float_as_int(p.src[1].sx), __float_as_int(p.src[2].sx)));
-    r.cbeg = m1 * c1 + m2 * (c2 - c1);
-    return r;
-}
-
-// load 4 consecutive channels of virtual pixel (n, vy, vx); zero outside the image / channel range.
-// Branch-free: the address is clamped into the tensor and the value is zeroed afterwards, so a batch of these
-// compiles to back-to-back global_load_dwordx4 without exec-mask regions (hipcc serialises predicated loads
-// with s_waitcnt vmcnt(0) between them).
-__device__ __forceinline__ f32x4 ssie_load_virtual(const SrcSel& s, int n, int vy, int vx, int Hv, int Wv, int c)
-{
-    const bool ok = vy >= 0 && vy < Hv && vx >= 0 && vx < Wv && c < s.C;
-    const int cy = min(max(vy, 0), Hv - 1), cx = min(max(vx, 0), Wv - 1), cc = min(c, s.C - 4);
-    const int y = min((int)floorf((float)cy * s.sy), s.Hs - 1);
-    const int x = min((int)floorf((float)cx * s.sx), s.Ws - 1);
-    f32x4 v = *(const f32x4*)(s.ptr + ((size_t)(n * s.Hs + y) * s.Ws + x) * s.cstride + s.coff + cc);
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    return ok ? v : z;
-}
 
 // ---------------------------------------------------------------------------------------------
 // fprop / dgrad
@@ -621,8 +573,12 @@ static int launch_fprop_t(const ConvParams& p, size_t lds, hipStream_t st)
     return hipGetLastError() == hipSuccess ? 0 : 14;
 }
 
+int ssie_fprop_use_v2 = 1;
+extern "C" void ssie_debug_set_fprop_v2(int v) { ssie_fprop_use_v2 = v; }
+
 int ssie_launch_fprop(const ConvParams& p, hipStream_t st)
 {
+    if (ssie_fprop_use_v2 && ssie_fprop_v2_ok(p)) return ssie_launch_fprop_v2(p, st);
     const int nt = (p.Cout_pad % 64 == 0) ? 2 : 1;
     if (p.Cout_pad % 32) return 11;
     if (p.ntaps < 1 || p.ntaps > SSIE_MAX_TAPS) return 12;

@@ -97,7 +97,8 @@ int ssie_make_conv(ConvParams& p, const SrcDesc* srcs, int nsrc, int N, int Hv, 
     p.min_dy = mny; p.min_dx = mnx;
     // 16-row tiles for the stride-1 layers with a small halo (3x3, 1x1, parity classes): half the weight staging,
     // barriers and tile boundaries per MFMA
-    p.th = (si == 1 && (mxy - mny) <= 2 && (mxx - mnx) <= 2 && Ho >= 16 && ssie_fprop_tile16) ? 16 : 8;
+    const int span = (mxy - mny) > (mxx - mnx) ? (mxy - mny) : (mxx - mnx);
+    p.th = (si == 1 && Ho >= 16 && Wo >= 16 && ((span <= 2 && ssie_fprop_tile16) || (span <= 8 && ssie_fprop_use_v2))) ? 16 : 8;
     p.hp_h = (p.th - 1) * si + (mxy - mny) + 1;
     p.hp_w = (SSIE_TW - 1) * si + (mxx - mnx) + 1;
     for (int i = 0; i < t.n; ++i) { p.tap_dy[i] = t.dy[i]; p.tap_dx[i] = t.dx[i]; }

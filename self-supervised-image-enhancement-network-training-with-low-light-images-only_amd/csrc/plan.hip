@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 #include <string.h>
+#include <stdio.h>
 #include <math.h>
 
 namespace {
@@ -24,8 +25,8 @@ typedef std::function<int(hipStream_t)> FnT;
 // op kinds for per-kernel-class profiling (bench.py roofline): see ssie_plan_profile_step
 enum { K_FPROP2 = 0, K_FPROP1, K_WGRAD, K_WGRAD_REDUCE, K_COLSUM, K_PACK, K_LOSS, K_FFT, K_ATTN, K_ELEMENTWISE, K_NKINDS };
 struct Fn {
-    FnT fn; int kind; double flops;
-    Fn(FnT f, int k = K_ELEMENTWISE, double fl = 0.0) : fn(std::move(f)), kind(k), flops(fl) {}
+    FnT fn; int kind; double flops; std::string tag;
+    Fn(FnT f, int k = K_ELEMENTWISE, double fl = 0.0, std::string t = "") : fn(std::move(f)), kind(k), flops(fl), tag(std::move(t)) {}
     int operator()(hipStream_t st) const { return fn(st); }
 };
 
@@ -179,7 +180,9 @@ struct Builder {
         if (pl.counter_cursor < 1024) p.tile_counter = (int*)(pl.ws + pl.counter_off) + pl.counter_cursor++;
         // algorithmic FLOPs: real (un-padded) channels and taps only
         const double fl = 2.0 * p.N * p.Ho * p.Wo * (double)p.Cout * k_real * p.ntaps;
-        ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_fprop(p, st); }, p.Cout_pad % 64 == 0 ? K_FPROP2 : K_FPROP1, fl));
+        char tag[96];
+        snprintf(tag, sizeof(tag), "conv k%d->n%d taps%d si%d so%d %dx%d", k_real, p.Cout, p.ntaps, p.si, p.so, p.Ho, p.Wo);
+        ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_fprop(p, st); }, p.Cout_pad % 64 == 0 ? K_FPROP2 : K_FPROP1, fl, tag));
     }
 
     // forward conv (stride 1/2) over concatenated / up-sampled sources
@@ -276,7 +279,9 @@ struct Builder {
         float* db = with_bias ? pl.G + L.b : nullptr;
         p.bias_slabs = bslab;
         const double fl = 2.0 * pl.N * Ho * Wo * (double)cout * creal * T;
-        ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_wgrad(p, st); }, K_WGRAD, fl));
+        char tag[96];
+        snprintf(tag, sizeof(tag), "wgrad ci%d co%d taps%d si%d %dx%d slices%d", creal, cout, T, stride, Ho, Wo, p.nslices);
+        ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_wgrad(p, st); }, K_WGRAD, fl, tag));
         ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, p.nslices, p.ntaps, p.ci_pad, p.co_pad, creal, cout, dw, s_co, T, 1, bslab, db, 1, st); }, K_WGRAD_REDUCE));
         return 0;
     }
@@ -711,6 +716,36 @@ extern "C" int ssie_plan_profile_step(void* h, const float* x, const long* strid
     }
     for (auto& e : ev) hipEventDestroy(e);
     return rc;
+}
+
+// per-launch variant of ssie_plan_profile_step (dev tool): ms/flops/kind per op in launch order + a '\n'-joined tag list
+extern "C" int ssie_plan_profile_ops(void* h, const float* x, const long* strides4, void* stream,
+                                     double* ms, double* flops, int* kinds, int cap, char* tags, int tags_cap)
+{
+    Plan* pl = (Plan*)h;
+    if (!pl || !pl->bound || !x || !strides4 || !pl->G) return -SSIE_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<const Fn*> seq;
+    for (auto& f : pl->fwd) seq.push_back(&f);
+    for (auto& f : pl->pass2) seq.push_back(&f);
+    for (auto& f : pl->lossbwd) seq.push_back(&f);
+    if ((int)seq.size() > cap) return -SSIE_E_WORKSPACE;
+    std::vector<hipEvent_t> ev(seq.size() + 1);
+    for (auto& e : ev) hipEventCreate(&e);
+    pack_all(pl, st); ingest(pl, x, strides4, st);
+    hipMemsetAsync(pl->G, 0, pl->nparam_floats * 4, st);
+    hipEventRecord(ev[0], st);
+    for (size_t i = 0; i < seq.size(); ++i) { (*seq[i])(st); hipEventRecord(ev[i + 1], st); }
+    hipStreamSynchronize(st);
+    std::string all;
+    for (size_t i = 0; i < seq.size(); ++i) {
+        float t = 0.f; hipEventElapsedTime(&t, ev[i], ev[i + 1]);
+        ms[i] = t; flops[i] = seq[i]->flops; kinds[i] = seq[i]->kind;
+        all += seq[i]->tag; all += "\n";
+    }
+    for (auto& e : ev) hipEventDestroy(e);
+    if (tags && tags_cap > 0) { strncpy(tags, all.c_str(), tags_cap - 1); tags[tags_cap - 1] = 0; }
+    return (int)seq.size();
 }
 
 extern "C" int ssie_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n,

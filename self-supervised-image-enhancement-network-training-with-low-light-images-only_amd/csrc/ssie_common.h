@@ -91,6 +91,9 @@ struct PackDesc {
 
 // host launchers (conv_kernels.hip); return 0 on success
 int ssie_launch_fprop(const ConvParams& p, hipStream_t st);
+bool ssie_fprop_v2_ok(const ConvParams& p);            // conv_fprop_v2.hip
+int ssie_launch_fprop_v2(const ConvParams& p, hipStream_t st);
+extern int ssie_fprop_use_v2;                          // tuning / A-B switch (1 = use the 512-thread DMA kernel when eligible)
 int ssie_launch_wgrad(const WgradParams& p, hipStream_t st);
 int ssie_launch_wgrad_reduce(const float* slabs, int nslices, int ntaps, int ci_pad, int co_pad, int Cin, int Cout,
                              float* dst, long s_co, long s_ci, long s_t, const float* bias_slabs, float* db,

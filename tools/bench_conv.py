@@ -21,6 +21,8 @@ def main():
     iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
     dev = "cuda"
     L = H.lib()
+    if os.environ.get('SSIE_V2') is not None:
+        L.ssie_debug_set_fprop_v2(int(os.environ['SSIE_V2']))
     if os.environ.get('SSIE_WGS'):
         L.ssie_debug_set_fprop_wgs_per_cu(int(os.environ['SSIE_WGS']))
     for (name, cin, cout, k, stride, hw) in [("conv1 64->64 3x3", 64, 64, 3, 1, 128), ("shallow 32->64 9x9", 32, 64, 9, 1, 128),
