@@ -122,8 +122,18 @@ def main():
         dom = max(agg, key=lambda k: agg[k][0])
         ms, fl, cnt = agg[dom]
         ach = fl / (ms * 1e-3) / 1e12
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the per-launch figure
+        # comes from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (profiles/)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))["kernels"]
+            cand = [v["hbm_bytes_per_launch"] * v["launches_sampled"] for k, v in tj.items() if k.startswith("conv_fprop")]
+            nl = sum(v["launches_sampled"] for k, v in tj.items() if k.startswith("conv_fprop"))
+            traffic = int(sum(cand) / nl) if nl else None
+        except Exception:
+            pass
         out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": None,
+                           "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic,
                            "launches_per_step": cnt // reps, "avg_launch_ms": round(ms / cnt, 4),
                            "algorithmic_gflop_per_step": round(fl / reps / 1e9, 1)}
         out["kernel_classes"] = {k: {"ms_per_step": round(v[0] / reps, 3), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[1] > 0 and v[0] > 0 else None,

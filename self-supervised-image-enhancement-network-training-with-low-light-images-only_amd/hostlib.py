@@ -280,7 +280,7 @@ class Plan:
     def loss_scalars(self) -> torch.Tensor:
         return self.buffer("scalars").reshape(7)
 
-    KINDS = ("conv_fprop_kernel<2>", "conv_fprop_kernel<1>", "conv_wgrad_kernel", "wgrad_reduce_kernel", "colsum",
+    KINDS = ("conv_fprop(+dgrad) 64-ch tile", "conv_fprop(+dgrad) 32-ch tile", "conv_wgrad_kernel", "wgrad_reduce_kernel", "colsum",
              "pack_weights", "loss_direct", "fft_loss_kernel", "attention", "elementwise")
 
     def profile_step(self, x):
