@@ -59,20 +59,44 @@ class FusedAdam(torch.optim.Optimizer):
         self.step_count += 1
         H.adam_step(flat, gflat, m, v, self.step_count, float(g["lr"]), grad_scale, g["betas"][0], g["betas"][1], g["eps"])
 
+    def reset_state(self):
+        """what re-creating torch.optim.Adam does (model.py:284): moments and step count start over"""
+        self.step_count = 0
+        if self.exp_avg is not None:
+            self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+
+    # checkpoint format == torch.optim.Adam's (model.py:595-607): per-parameter 'step' / 'exp_avg' / 'exp_avg_sq'
     def state_dict(self):
-        sd = super().state_dict()
-        sd["ssie_flat"] = dict(step=self.step_count,
-                               exp_avg=None if self.exp_avg is None else self.exp_avg.detach().cpu(),
-                               exp_avg_sq=None if self.exp_avg_sq is None else self.exp_avg_sq.detach().cpu())
-        return sd
+        o = self._owner
+        state = {}
+        if self.exp_avg is not None and self.step_count > 0:
+            for i, ((name, off, shape), p) in enumerate(zip(o._table, o._plist)):
+                n = p.numel()
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.exp_avg[off:off + n].view(shape).detach().clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + n].view(shape).detach().clone()}
+        g = self.param_groups[0]
+        group = {"lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(o._plist)))}
+        if "initial_lr" in g:
+            group["initial_lr"] = g["initial_lr"]
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        sd = dict(sd)
-        flat = sd.pop("ssie_flat", None)
-        super().load_state_dict(sd)
-        if flat is not None:
-            self.step_count = int(flat["step"])
-            self.exp_avg, self.exp_avg_sq = flat["exp_avg"], flat["exp_avg_sq"]
+        o = self._owner
+        o._ensure_device_layout()
+        m, v = self._buffers()
+        m.zero_(); v.zero_(); self.step_count = 0
+        for i, st in sd.get("state", {}).items():
+            name, off, shape = o._table[int(i)]
+            n = o._plist[int(i)].numel()
+            m[off:off + n].copy_(st["exp_avg"].reshape(-1).to(m.device))
+            v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1).to(v.device))
+            self.step_count = max(self.step_count, int(float(st["step"])))
+        groups = sd.get("param_groups") or []
+        if groups:
+            self.param_groups[0]["lr"] = groups[0].get("lr", self.param_groups[0]["lr"])
 
 
 class _LossFn(torch.autograd.Function):
@@ -129,6 +153,8 @@ class LowLightEnhance(nn.Module):
         self._gflat = None
         self._plist = []
         self._plans = {}
+        self._decomp_frozen = False
+        self._illum_off = next(off for (name, off, shape) in self._table if name.startswith("illum_adjust_net."))
         self._build_tree()
         self._default_init()
         self.optimizer = FusedAdam(self, lr=lr)
@@ -237,6 +263,8 @@ class LowLightEnhance(nn.Module):
         x = self._f32(input_low)
         plan = self._plan_for(x)
         plan.loss_fwd_bwd(x, backward=True)
+        if self._decomp_frozen:
+            self._gflat[:self._illum_off].zero_()                # frozen DecompositionNet (model.py:274-279): no update
         gscale = dp.allreduce_flat_(self._gflat, world_size)   # one flat fp32 buffer over RCCL / xGMI
         opt = self.optimizer
         m, v = opt._buffers()
@@ -245,6 +273,16 @@ class LowLightEnhance(nn.Module):
         H.adam_step(self._flat, self._gflat, m, v, opt.step_count, float(g["lr"]), gscale,
                     g["betas"][0], g["betas"][1], g["eps"])
         return plan.loss_scalars()
+
+    def set_decomposition_frozen(self, frozen: bool):
+        """freeze_decom_epochs semantics (model.py:274-288): frozen => DecompositionNet gets no updates; on the
+        frozen -> unfrozen transition the reference re-creates Adam, i.e. all optimiser state starts over."""
+        frozen = bool(frozen)
+        if self._decomp_frozen and not frozen:
+            self.optimizer.reset_state()
+        self._decomp_frozen = frozen
+        for p in self.decomposition_net.parameters():
+            p.requires_grad = not frozen
 
     def flat_parameters(self):
         self._ensure_device_layout()
@@ -265,6 +303,9 @@ class LowLightEnhance(nn.Module):
         print(f"Checkpoint saved at {path}")
 
     def load_checkpoint(self, path):
+        """model.py:603-607; tensors-only loader (never unpickles code)"""
         ck = torch.load(path, map_location=self._plist[0].device, weights_only=True)
         self.load_state_dict(ck["model_state_dict"])
+        if "optimizer_state_dict" in ck:
+            self.optimizer.load_state_dict(ck["optimizer_state_dict"])
         print(f"Loaded checkpoint from {path}")
