@@ -270,6 +270,7 @@ class LowLightEnhance(nn.Module):
         m, v = opt._buffers()
         g = opt.param_groups[0]
         opt.step_count += 1
+        opt._opt_called = True                                   # lets torch's StepLR know a step happened
         H.adam_step(self._flat, self._gflat, m, v, opt.step_count, float(g["lr"]), gscale,
                     g["betas"][0], g["betas"][1], g["eps"])
         return plan.loss_scalars()
