@@ -300,13 +300,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     constexpr int MI = CIB / 32, NI = COB / 32, NPAIR = MI * NI, WSPLIT = 4 / NPAIR;
-    const int HP = p.hp_h * p.hp_w;
     const int PT = p.th * SSIE_TW;
-    float* Xs = smem_f;                 // [HP][CIB]
-    float* Gs = Xs + HP * CIB;          // [PT][COB]
+    float* Xs = smem_f;                           // [HP][CIB]   (HP = rows needed by THIS tap group x hp_w)
+    float* Gs = Xs + p.hp_h * p.hp_w * CIB;       // [PT][COB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, li = lane & 31;
+    // every wave owns one (ci-tile, co-tile) pair and ALL taps of the group; waves that share a pair split the
+    // positions (K) between them and write separate partial slabs - no tap imbalance, no idle wave
     const int pair = wave % NPAIR, wsub = wave / NPAIR;
     const int mi = pair / NI, ni = pair % NI;
     const int slice = blockIdx.x;
@@ -315,14 +316,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     const int tg = min(SSIE_TG, p.ntaps - t0);
     const int ci0 = cib * CIB, co0 = cob * COB;
 
+    // halo rows actually touched by this tap group (one kernel row of the 9x9 => 8 rows instead of 16)
+    int gmin_dy = 127, gmax_dy = -127;
+    for (int tl = 0; tl < tg; ++tl) { const int dy = p.tap_dy[t0 + tl]; gmin_dy = min(gmin_dy, dy); gmax_dy = max(gmax_dy, dy); }
+    const int rows = (p.th - 1) * p.si + (gmax_dy - gmin_dy) + 1;
+    const int HP = rows * p.hp_w;
+
     int toff[NU];
     bool tval[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-        int tl = wsub * NU + u;
-        tval[u] = tl < tg;
-        int t = t0 + (tval[u] ? tl : 0);
-        toff[u] = (((int)p.tap_dy[t] - p.min_dy) * p.hp_w + ((int)p.tap_dx[t] - p.min_dx)) * CIB + mi * 32 + li;
+        tval[u] = u < tg;
+        const int t = t0 + (tval[u] ? u : 0);
+        toff[u] = (((int)p.tap_dy[t] - gmin_dy) * p.hp_w + ((int)p.tap_dx[t] - p.min_dx)) * CIB + mi * 32 + li;
     }
     f32x16 acc[NU];
 #pragma unroll
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         const int ty = tt % p.tiles_y;
         const int n = tt / p.tiles_y;
         const int a0 = ty * p.th, b0 = tx * SSIE_TW;
-        const int vy0 = a0 * p.si + p.min_dy, vx0 = b0 * p.si + p.min_dx;
+        const int vy0 = a0 * p.si + gmin_dy, vx0 = b0 * p.si + p.min_dx;
         __syncthreads();
         // staging in batches of UB independent 16-byte loads per thread so the global latency is paid once per
         // batch, not once per element
@@ -397,8 +403,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         __syncthreads();
         if (do_bias)
             for (int px = brow; px < PT; px += BROWS) bsum += Gs[px * COB + bcol];
+        // MFMA K loop over position pairs (this wave's share: kp = wsub, wsub + WSPLIT, ...)
         const int npair = PT / 2;
-        for (int kp = 0; kp < npair; ++kp) {
+        for (int kp = wsub; kp < npair; kp += WSPLIT) {
             const int pix = 2 * kp + h;
             const int xbase = ((pix / SSIE_TW) * p.si * p.hp_w + (pix % SSIE_TW) * p.si) * CIB;
             const float b = Gs[pix * COB + ni * 32 + li];
@@ -421,11 +428,32 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
             p.bias_slabs[(size_t)slice * p.co_pad + co0 + tid] = t;
         }
     }
-    // partial slab [slice][tap][ci_pad][co_pad]; row (M) = ci, col (N) = co
+    // waves that shared a tile pair add their partial accumulators through LDS (fixed order => deterministic), so the
+    // workgroup writes ONE partial slab [slice][tap][ci_pad][co_pad]; row (M) = ci, col (N) = co
+    if (WSPLIT > 1) {
+        float* red = smem_f;                      // NPAIR x NU x 16 x 64 floats <= 36.9 KB, inside the staging area
+        for (int w = 1; w < WSPLIT; ++w) {
+            __syncthreads();
+            if (wsub == w) {
+#pragma unroll
+                for (int u = 0; u < NU; ++u)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((pair * NU + u) * 16 + r) * 64 + lane] = acc[u][r];
+            }
+            __syncthreads();
+            if (wsub == 0) {
+#pragma unroll
+                for (int u = 0; u < NU; ++u)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[u][r] += red[((pair * NU + u) * 16 + r) * 64 + lane];
+            }
+        }
+        if (wsub != 0) return;
+    }
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         if (!tval[u]) continue;
-        const int t = t0 + wsub * NU + u;
+        const int t = t0 + u;
         float* dst = p.slabs + (((size_t)slice * p.ntaps + t) * p.ci_pad + ci0 + mi * 32) * p.co_pad + co0 + ni * 32 + li;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -437,9 +465,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 
 #define INST_WGRAD(CI, CO, NU) template __global__ void conv_wgrad_kernel<CI, CO, NU>(const WgradParams);
 INST_WGRAD(64, 64, 9) INST_WGRAD(64, 64, 1)
-INST_WGRAD(32, 64, 5) INST_WGRAD(32, 64, 1)
-INST_WGRAD(64, 32, 5) INST_WGRAD(64, 32, 1)
-INST_WGRAD(32, 32, 3) INST_WGRAD(32, 32, 1)
+INST_WGRAD(32, 64, 9) INST_WGRAD(32, 64, 1)
+INST_WGRAD(64, 32, 9) INST_WGRAD(64, 32, 1)
+INST_WGRAD(32, 32, 9) INST_WGRAD(32, 32, 1)
 
 // dst[co*s_co + ci*s_ci + t*s_t] (+)= sum_slices slab[slice][t][ci][co]; the trailing Cout outputs are the fused
 // bias gradient db[co] (+)= sum_slices bias_slab[slice][co].  64 outputs x 4 slice groups per block, fixed order
@@ -599,6 +627,11 @@ template <int CI, int CO, int NU>
 static int launch_wgrad_t(const WgradParams& p, hipStream_t st)
 {
     size_t lds = ((size_t)p.hp_h * p.hp_w * CI + (size_t)p.th * SSIE_TW * CO) * 4;
+    constexpr int NPAIR = (CI / 32) * (CO / 32);
+    if (NPAIR < 4) {                                   // scratch of the in-workgroup K-split reduction
+        const size_t red = (size_t)NPAIR * NU * 16 * 64 * 4;
+        if (lds < red) lds = red;
+    }
     if (lds > 160 * 1024) return 23;
     static bool set = false;
     if (!set) { hipFuncSetAttribute((const void*)conv_wgrad_kernel<CI, CO, NU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
@@ -613,9 +646,9 @@ int ssie_launch_wgrad(const WgradParams& p, hipStream_t st)
     const int cib = p.ci_pad / p.ci_blocks, cob = p.co_pad / p.co_blocks;
     const bool one = p.ntaps == 1;
     if (cib == 64 && cob == 64) return one ? launch_wgrad_t<64, 64, 1>(p, st) : launch_wgrad_t<64, 64, 9>(p, st);
-    if (cib == 32 && cob == 64) return one ? launch_wgrad_t<32, 64, 1>(p, st) : launch_wgrad_t<32, 64, 5>(p, st);
-    if (cib == 64 && cob == 32) return one ? launch_wgrad_t<64, 32, 1>(p, st) : launch_wgrad_t<64, 32, 5>(p, st);
-    if (cib == 32 && cob == 32) return one ? launch_wgrad_t<32, 32, 1>(p, st) : launch_wgrad_t<32, 32, 3>(p, st);
+    if (cib == 32 && cob == 64) return one ? launch_wgrad_t<32, 64, 1>(p, st) : launch_wgrad_t<32, 64, 9>(p, st);
+    if (cib == 64 && cob == 32) return one ? launch_wgrad_t<64, 32, 1>(p, st) : launch_wgrad_t<64, 32, 9>(p, st);
+    if (cib == 32 && cob == 32) return one ? launch_wgrad_t<32, 32, 1>(p, st) : launch_wgrad_t<32, 32, 9>(p, st);
     return 21;
 }
 

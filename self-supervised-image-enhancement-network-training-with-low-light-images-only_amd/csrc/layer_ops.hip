@@ -130,6 +130,7 @@ int ssie_make_wgrad(WgradParams& p, const SrcDesc& src, int N, int Hv, int Wv, i
     const int cib = src.C > 32 ? 64 : 32, cob = Cout > 32 ? 64 : 32;
     p.ci_blocks = ssie_ceil_div(src.C, cib); p.co_blocks = ssie_ceil_div(Cout, cob);
     p.ci_pad = p.ci_blocks * cib; p.co_pad = p.co_blocks * cob;
+    p.wsplit = 4 / ((cib / 32) * (cob / 32));
     p.tap_groups = ssie_ceil_div(t.n, SSIE_TG);
     p.tiles_y = ssie_ceil_div(Ho, p.th); p.tiles_x = ssie_ceil_div(Wo, SSIE_TW);
     p.tiles_total = N * p.tiles_y * p.tiles_x;

@@ -80,6 +80,7 @@ struct WgradParams {
     int ci_pad, co_pad;
     int nslices, tiles_total, tiles_y, tiles_x, th;
     int ci_blocks, co_blocks, tap_groups;
+    int wsplit;             // waves sharing one (ci,co) tile pair = partial slabs written per workgroup (4 / tile pairs)
 };
 
 struct PackDesc {
