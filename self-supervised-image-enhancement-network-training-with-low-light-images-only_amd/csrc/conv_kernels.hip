@@ -469,75 +469,86 @@ INST_WGRAD(32, 64, 9) INST_WGRAD(32, 64, 1)
 INST_WGRAD(64, 32, 9) INST_WGRAD(64, 32, 1)
 INST_WGRAD(32, 32, 9) INST_WGRAD(32, 32, 1)
 
-// dst[co*s_co + ci*s_ci + t*s_t] (+)= sum_slices slab[slice][t][ci][co]; the trailing Cout outputs are the fused
-// bias gradient db[co] (+)= sum_slices bias_slab[slice][co].  64 outputs x 4 slice groups per block, fixed order
-// (deterministic, bit-reproducible across runs and ranks).
+// dst[co*s_co + ci*s_ci + t*s_t] (+)= sum_slices slab[slice][t][ci][co]; the trailing rows are the fused bias gradient
+// db[co] (+)= sum_slices bias_slab[slice][co].  Each thread owns 4 consecutive co (one 16-byte load per slice);
+// 64 output quads x 4 slice groups per block, fixed summation order (deterministic, identical on every rank).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int nslices, int ntaps, int ci_pad, int co_pad,
                                     int Cin, int Cout, float* __restrict__ dst, long s_co, long s_ci, long s_t,
                                     const float* __restrict__ bias_slabs, float* __restrict__ db, int accumulate)
 {
-    __shared__ float red[4][64];
+    __shared__ f32x4 red[4][64];
     const int lo = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int cq = (Cout + 3) / 4;                                 // channel quads per (tap, ci) row
     const long idx = (long)blockIdx.x * 64 + lo;
-    const long total = (long)ntaps * Cin * Cout;
-    const long total_b = total + (bias_slabs ? Cout : 0);
-    float sum = 0.f;
-    float* d = nullptr;
+    const long total = (long)ntaps * Cin * cq;
+    const long total_b = total + (bias_slabs ? cq : 0);
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    int co = 0, ci = 0, t = 0;
+    bool is_w = false, is_b = false;
     if (idx < total) {
-        const int co = (int)(idx % Cout);
-        const int ci = (int)((idx / Cout) % Cin);
-        const int t = (int)(idx / ((long)Cout * Cin));
+        is_w = true;
+        co = (int)(idx % cq) * 4; ci = (int)((idx / cq) % Cin); t = (int)(idx / ((long)cq * Cin));
         const size_t slab_sz = (size_t)ntaps * ci_pad * co_pad;
         const float* sp = slabs + ((size_t)t * ci_pad + ci) * co_pad + co;
-        for (int s = sg; s < nslices; s += 4) sum += sp[(size_t)s * slab_sz];
-        d = dst + co * s_co + ci * s_ci + t * s_t;
+        // 8 independent loads in flight per thread (the slabs are 100+ KB apart: latency-, not bandwidth-bound otherwise)
+        int s = sg;
+        for (; s + 28 < nslices; s += 32) {
+            f32x4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = *(const f32x4*)(sp + (size_t)(s + 4 * q) * slab_sz);
+            sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        for (; s < nslices; s += 4) sum += *(const f32x4*)(sp + (size_t)s * slab_sz);
     } else if (idx < total_b) {
-        const int co = (int)(idx - total);
-        for (int s = sg; s < nslices; s += 4) sum += bias_slabs[(size_t)s * co_pad + co];
-        d = db + co;
+        is_b = true;
+        co = (int)(idx - total) * 4;
+        for (int s = sg; s < nslices; s += 4) sum += *(const f32x4*)(bias_slabs + (size_t)s * co_pad + co);
     }
     red[sg][lo] = sum;
     __syncthreads();
-    if (sg == 0 && d) {
-        const float tot = (red[0][lo] + red[1][lo]) + (red[2][lo] + red[3][lo]);
-        *d = accumulate ? (*d + tot) : tot;
+    if (sg == 0 && (is_w || is_b)) {
+        const f32x4 tot = (red[0][lo] + red[1][lo]) + (red[2][lo] + red[3][lo]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (co + k >= Cout) break;
+            float* d = is_w ? dst + (co + k) * s_co + ci * s_ci + t * s_t : db + co + k;
+            *d = accumulate ? (*d + tot[k]) : tot[k];
+        }
     }
 }
 
-// per-channel sums of G over all pixels (bias gradient), two-stage & deterministic
-__global__ void colsum_partial_kernel(const float* __restrict__ g, long npix, int cstride, int coff, int C,
+// per-channel sums of G over all pixels (bias gradient of the transposed conv), two-stage & deterministic.
+// Stage 1: block = 64 channels x 4 pixel lanes, coalesced 256-byte rows; stage 2: one block per channel reduces the
+// per-block partials with 256 threads.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ g, long npix, int cstride, int coff, int C,
                                       float* __restrict__ partial /*[gridDim.x][C]*/)
 {
-    __shared__ float red[256];
-    const int tid = threadIdx.x;
-    int cw = 1; while (cw < C) cw <<= 1; if (cw > 256) cw = 256;
-    const int lanes = 256 / cw;
-    const int pl = tid / cw, cl = tid % cw;
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
     const long per = (npix + gridDim.x - 1) / gridDim.x;
     const long beg = (long)blockIdx.x * per, end = min(beg + per, npix);
-    for (int c0 = 0; c0 < C; c0 += cw) {
+    for (int c0 = 0; c0 < C; c0 += 64) {
         const int c = c0 + cl;
         float sum = 0.f;
         if (c < C)
-            for (long px = beg + pl; px < end; px += lanes) sum += g[px * cstride + coff + c];
-        red[tid] = sum;
+            for (long px = beg + pl; px < end; px += 4) sum += g[px * cstride + coff + c];
+        red[pl][cl] = sum;
         __syncthreads();
-        if (pl == 0 && c < C) {
-            float tot = 0.f;
-            for (int q = 0; q < lanes; ++q) tot += red[q * cw + cl];
-            partial[(size_t)blockIdx.x * C + c] = tot;
-        }
+        if (pl == 0 && c < C) partial[(size_t)blockIdx.x * C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
         __syncthreads();
     }
 }
 
-__global__ void colsum_final_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ dst, int accumulate)
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ dst, int accumulate)
 {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float red[256];
+    const int c = blockIdx.x, t = threadIdx.x;
     float sum = 0.f;
-    for (int b = 0; b < nblk; ++b) sum += partial[(size_t)b * C + c];
-    dst[c] = accumulate ? dst[c] + sum : sum;
+    for (int b = t; b < nblk; b += 256) sum += partial[(size_t)b * C + c];
+    red[t] = sum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+    if (t == 0) dst[c] = accumulate ? dst[c] + red[0] : red[0];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -656,7 +667,8 @@ int ssie_launch_wgrad_reduce(const float* slabs, int nslices, int ntaps, int ci_
                              float* dst, long s_co, long s_ci, long s_t, const float* bias_slabs, float* db,
                              int accumulate, hipStream_t st)
 {
-    long total = (long)ntaps * Cin * Cout + (bias_slabs ? Cout : 0);
+    const long cq = (Cout + 3) / 4;
+    long total = (long)ntaps * Cin * cq + (bias_slabs ? cq : 0);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st,
                        slabs, nslices, ntaps, ci_pad, co_pad, Cin, Cout, dst, s_co, s_ci, s_t, bias_slabs, db, accumulate);
     return hipGetLastError() == hipSuccess ? 0 : 25;
@@ -666,7 +678,7 @@ int ssie_launch_colsum(const float* g, long npix, int cstride, int coff, int C, 
                        float* dst, int accumulate, hipStream_t st)
 {
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, st, g, npix, cstride, coff, C, partial);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial, nblk, C, dst, accumulate);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(256), 0, st, partial, nblk, C, dst, accumulate);
     return hipGetLastError() == hipSuccess ? 0 : 26;
 }
 

@@ -139,26 +139,31 @@ __global__ __launch_bounds__(256) void loss_direct_kernel(const LossParams p)
     }
 }
 
-// terms[0..5] = (rec, rf, il, id, fourier, sp); out[0] = total, out[1..6] = terms in LOSS order
-__global__ void loss_finalize_kernel(const float* __restrict__ partials, int nblk,
+// terms[0..5] = (rec, rf, il, id, fourier, sp); out[0] = total, out[1..6] = terms in LOSS order.
+// One 256-thread block; fixed-order tree reduction in double => deterministic.
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ partials, int nblk,
                                      const float* __restrict__ fpartials, int nfblk,
                                      float c_rec, float c_rf, float c_il, float c_id, float c_f, float c_sp,
                                      float* __restrict__ out)
 {
-    __shared__ double sums[6];
+    __shared__ double red[6][256];
     const int t = threadIdx.x;
-    if (t < 5) {
-        double s = 0.0;
-        for (int b = 0; b < nblk; ++b) s += (double)partials[(size_t)b * 8 + t];
-        sums[t] = s;
-    } else if (t == 5) {
-        double s = 0.0;
-        for (int b = 0; b < nfblk; ++b) s += (double)fpartials[b];
-        sums[5] = s;
-    }
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    for (int b = t; b < nblk; b += 256)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) s[k] += (double)partials[(size_t)b * 8 + k];
+    for (int b = t; b < nfblk; b += 256) s[5] += (double)fpartials[b];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) red[k][t] = s[k];
     __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) red[k][t] += red[k][t + o];
+        __syncthreads();
+    }
     if (t == 0) {
-        const double rec = sums[0], rf = sums[1], il = sums[2], id = sums[3], sp = sums[4], f = sums[5];
+        const double rec = red[0][0], rf = red[1][0], il = red[2][0], id = red[3][0], sp = red[4][0], f = red[5][0];
         out[0] = (float)(c_rec * rec + c_rf * rf + c_il * il + c_id * id + c_f * f + c_sp * sp);
         out[1] = (float)rec; out[2] = (float)rf; out[3] = (float)il; out[4] = (float)id; out[5] = (float)f; out[6] = (float)sp;
     }
@@ -282,7 +287,7 @@ int ssie_launch_loss_direct(const LossParams& p, int nblk, hipStream_t st)
 int ssie_launch_loss_finalize(const float* partials, int nblk, const float* fpartials, int nfblk,
                               const float* coefs6, float* out, hipStream_t st)
 {
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, partials, nblk, fpartials, nfblk,
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, partials, nblk, fpartials, nfblk,
                        coefs6[0], coefs6[1], coefs6[2], coefs6[3], coefs6[4], coefs6[5], out);
     return hipGetLastError() == hipSuccess ? 0 : 42;
 }
