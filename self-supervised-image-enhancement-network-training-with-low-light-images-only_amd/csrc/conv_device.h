@@ -50,3 +50,62 @@ __device__ __forceinline__ f32x4 ssie_load_virtual(const SrcSel& s, int n, int v
     return ok ? v : z;
 }
 
+
+// Epilogue of one 32 x 32 accumulator tile whose 2 x 16 output positions all lie inside the output (the caller checked).
+// C/D layout: register r of a lane holds tile row r>>3, tile column (r&3) + 8*((r>>2)&1) (+4h, already in o0); every
+// element offset is a compile-time multiple of two run-time strides.  The fused extras (activation-derivative mask,
+// second output, residual add, accumulate) are applied in the same order as the general path, but each one loads its
+// 16 operands back-to-back BEFORE using them: a load -> use -> store chain per element exposes one HBM latency per
+// element (16-32 per tile), which is what made the masked data-gradient launches ~40 % slower than the plain ones.
+#define SSIE_EOFF(r) ((long)((r) >> 3) * rowstride + (long)(((r) & 3) + 8 * (((r) >> 2) & 1)) * pixstride)
+template <typename PT>
+__device__ __forceinline__ void ssie_epilogue_full(const PT& p, const f32x16& acc, size_t o0, long rowstride, long pixstride, float bv)
+{
+    float v[16];
+    if (p.act == ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[r] + bv, 0.f);
+    } else if (p.act == ACT_SIGMOID) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = 1.f / (1.f + expf(-(acc[r] + bv)));
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[r] + bv;
+    }
+    if (p.mask_mode != MASK_NONE) {
+        const float* mp = p.mask_y + o0;
+        float y[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[r] = mp[SSIE_EOFF(r)];
+        if (p.mask_mode == MASK_RELU) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = y[r] > 0.f ? v[r] : 0.f;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] *= y[r] * (1.f - y[r]);
+        }
+    }
+    if (p.out2) {
+        float* o2 = p.out2 + o0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o2[SSIE_EOFF(r)] = v[r];
+    }
+    if (p.addsrc) {
+        const float* ap = p.addsrc + o0;
+        float a[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = ap[SSIE_EOFF(r)];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += a[r];
+    }
+    float* ob = p.out + o0;
+    if (p.accumulate) {
+        float a[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = ob[SSIE_EOFF(r)];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += a[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ob[SSIE_EOFF(r)] = v[r];
+}

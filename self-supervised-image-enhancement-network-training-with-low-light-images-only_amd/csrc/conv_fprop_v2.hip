@@ -202,7 +202,6 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_v2_kernel(const ConvParams 
             const float bv = p.bias ? p.bias[co] : 0.f;
             const long rowstride = (long)p.so * p.Wout * p.out_cstride;
             const long pixstride = (long)p.so * p.out_cstride;
-            const bool simple = p.mask_mode == MASK_NONE && !p.out2 && !p.addsrc && !p.accumulate;
             const bool full = a0 + TH <= p.Ho && b0 + SSIE_TW <= p.Wo &&
                               (a0 + TH - 1) * p.so + p.py < p.Hout && (b0 + SSIE_TW - 1) * p.so + p.px < p.Wout;
 #pragma unroll
@@ -210,20 +209,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_v2_kernel(const ConvParams 
                 const int mt = wm * MT + m;
                 const int arow = a0 + 2 * mt, bcol = b0 + 4 * h;
                 const size_t o0 = ((size_t)(n * p.Hout + arow * p.so + p.py) * p.Wout + bcol * p.so + p.px) * p.out_cstride + p.out_coff + co;
-                if (simple && full) {
-                    float* ob = p.out + o0;
-                    if (p.act == ACT_RELU) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) ob[(r >> 3) * rowstride + ((r & 3) + 8 * ((r >> 2) & 1)) * pixstride] = fmaxf(acc[m][r] + bv, 0.f);
-                    } else if (p.act == ACT_NONE) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) ob[(r >> 3) * rowstride + ((r & 3) + 8 * ((r >> 2) & 1)) * pixstride] = acc[m][r] + bv;
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) ob[(r >> 3) * rowstride + ((r & 3) + 8 * ((r >> 2) & 1)) * pixstride] = 1.f / (1.f + expf(-(acc[m][r] + bv)));
-                    }
-                    continue;
-                }
+                if (full) { ssie_epilogue_full(p, acc[m], o0, rowstride, pixstride, bv); continue; }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int tr = r >> 3, tc = (r & 3) + 8 * ((r >> 2) & 1);
