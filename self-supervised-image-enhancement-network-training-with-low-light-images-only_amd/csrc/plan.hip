@@ -26,7 +26,8 @@ typedef std::function<int(hipStream_t)> FnT;
 enum { K_FPROP2 = 0, K_FPROP1, K_WGRAD, K_WGRAD_REDUCE, K_COLSUM, K_PACK, K_LOSS, K_FFT, K_ATTN, K_ELEMENTWISE, K_NKINDS };
 struct Fn {
     FnT fn; int kind; double flops; std::string tag;
-    Fn(FnT f, int k = K_ELEMENTWISE, double fl = 0.0, std::string t = "") : fn(std::move(f)), kind(k), flops(fl), tag(std::move(t)) {}
+    int slab = 0;       // K_WGRAD / K_WGRAD_REDUCE: which of the two slab areas the launch writes / reads
+    Fn(FnT f, int k = K_ELEMENTWISE, double fl = 0.0, std::string t = "", int sl = 0) : fn(std::move(f)), kind(k), flops(fl), tag(std::move(t)), slab(sl) {}
     int operator()(hipStream_t st) const { return fn(st); }
 };
 
@@ -44,7 +45,7 @@ struct Plan {
     size_t nparam_floats = 0;
     std::map<std::string, BufInfo> bufs;
     size_t ws_floats = 0;
-    size_t slab_off = 0, slab_cap = 0, partial_off = 0, packdesc_off = 0, mask_off = 0, scal_off = 0;
+    size_t slab_off = 0, slab_off2 = 0, slab_cap = 0, partial_off = 0, packdesc_off = 0, mask_off = 0, scal_off = 0;
     size_t lpart_off = 0, fpart_off = 0, counter_off = 0;
     int counter_cursor = 0;
     int loss_blocks = 0, fft_blocks = 0;
@@ -55,6 +56,15 @@ struct Plan {
     size_t pack_cursor = 0, pack_floats_total = 0, pack_off = 0;
     std::vector<Fn> fwd, pass2, lossbwd;
     bool bound = false;
+    // the slab reductions (HBM-bound) run on a side stream underneath the next MFMA-bound launches; wgrad launches
+    // alternate between two slab areas so that a reduction only has to finish before the wgrad AFTER the next one
+    int slab_seq = 0;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_w[2] = {nullptr, nullptr}, ev_r[2] = {nullptr, nullptr};
+    ~Plan() {
+        for (int i = 0; i < 2; ++i) { if (ev_w[i]) hipEventDestroy(ev_w[i]); if (ev_r[i]) hipEventDestroy(ev_r[i]); }
+        if (side) hipStreamDestroy(side);
+    }
 
     float* buf(const char* n) { return ws + bufs.at(n).off; }
     const BufInfo& bi(const char* n) { return bufs.at(n); }
@@ -143,6 +153,7 @@ void build_buffers(Plan& pl)
     // scratch
     pl.slab_cap = (size_t)kWgs * 9 * 64 * 64 + (size_t)81 * ssie_round_up(B + 1, 64) * 128 + (size_t)kWgs * ssie_round_up(B + 1, 64);
     pl.slab_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + pl.slab_cap, 64);
+    pl.slab_off2 = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + pl.slab_cap, 64);
     pl.partial_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 256 * 256, 64);
     pl.loss_blocks = 2048; pl.fft_blocks = ssie_fft_grid(N, B);
     pl.lpart_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + (size_t)pl.loss_blocks * 8, 64);
@@ -267,22 +278,24 @@ struct Builder {
         if (Ho != gb.H || Wo != gb.W) return SSIE_E_SHAPE;
         TapList t = ssie_taps_conv(L.k);
         WgradParams p;
-        int rc = ssie_make_wgrad(p, x, pl.N, Hv, Wv, 0, pl.buf(g), gb.cs, g_coff, L.cout, Ho, Wo, stride, t, pl.ws + pl.slab_off, kWgs);
+        const int sl = pl.slab_seq++ & 1;
+        const size_t soff = sl ? pl.slab_off2 : pl.slab_off;
+        int rc = ssie_make_wgrad(p, x, pl.N, Hv, Wv, 0, pl.buf(g), gb.cs, g_coff, L.cout, Ho, Wo, stride, t, pl.ws + soff, kWgs);
         if (rc) return rc;
         const size_t need = ssie_wgrad_slab_floats(p);
         if (need + (size_t)p.nslices * p.co_pad > pl.slab_cap) return SSIE_E_WORKSPACE;
         float* dw = pl.G + L.w + (size_t)ci_off * T;
         const long s_co = (long)L.cin * T;
-        const float* slabs = pl.ws + pl.slab_off;
+        const float* slabs = pl.ws + soff;
         const int cout = L.cout;
-        float* bslab = with_bias ? pl.ws + pl.slab_off + need : nullptr;
+        float* bslab = with_bias ? pl.ws + soff + need : nullptr;
         float* db = with_bias ? pl.G + L.b : nullptr;
         p.bias_slabs = bslab;
         const double fl = 2.0 * pl.N * Ho * Wo * (double)cout * creal * T;
         char tag[96];
         snprintf(tag, sizeof(tag), "wgrad ci%d co%d taps%d si%d %dx%d slices%d", creal, cout, T, stride, Ho, Wo, p.nslices);
-        ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_wgrad(p, st); }, K_WGRAD, fl, tag));
-        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, p.nslices, p.ntaps, p.ci_pad, p.co_pad, creal, cout, dw, s_co, T, 1, bslab, db, 1, st); }, K_WGRAD_REDUCE));
+        ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_wgrad(p, st); }, K_WGRAD, fl, tag, sl));
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, p.nslices, p.ntaps, p.ci_pad, p.co_pad, creal, cout, dw, s_co, T, 1, bslab, db, 1, st); }, K_WGRAD_REDUCE, 0.0, "", sl));
         return 0;
     }
 
@@ -399,11 +412,13 @@ int build_decomposition_bwd(Builder& b, std::vector<Fn>& ops, const char* xin, i
         SrcDesc gs = b.src("Gdc", 64, H, W);
         WgradParams wp; TapList t = ssie_taps_conv(3);
         const BufInfo& cb = pl.bi(c3.c_str());
-        CK(ssie_make_wgrad(wp, gs, pl.N, H, W, 0, pl.buf(c3.c_str()), cb.cs, 0, 128, H2, W2, 2, t, pl.ws + pl.slab_off, kWgs));
+        const int sl = pl.slab_seq++ & 1;
+        const size_t soff = sl ? pl.slab_off2 : pl.slab_off;
+        CK(ssie_make_wgrad(wp, gs, pl.N, H, W, 0, pl.buf(c3.c_str()), cb.cs, 0, 128, H2, W2, 2, t, pl.ws + soff, kWgs));
         if (ssie_wgrad_slab_floats(wp) > pl.slab_cap) return SSIE_E_WORKSPACE;
-        float* dw = pl.G + Ld.w; const float* slabs = pl.ws + pl.slab_off;
-        ops.push_back(Fn([wp](hipStream_t st) { return ssie_launch_wgrad(wp, st); }, K_WGRAD, 2.0 * pl.N * H2 * W2 * 128.0 * 64 * 9));
-        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, wp.nslices, wp.ntaps, wp.ci_pad, wp.co_pad, 64, 128, dw, 64L * 9, 9, 1, nullptr, nullptr, 1, st); }, K_WGRAD_REDUCE));
+        float* dw = pl.G + Ld.w; const float* slabs = pl.ws + soff;
+        ops.push_back(Fn([wp](hipStream_t st) { return ssie_launch_wgrad(wp, st); }, K_WGRAD, 2.0 * pl.N * H2 * W2 * 128.0 * 64 * 9, "", sl));
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, wp.nslices, wp.ntaps, wp.ci_pad, wp.co_pad, 64, 128, dw, 64L * 9, 9, 1, nullptr, nullptr, 1, st); }, K_WGRAD_REDUCE, 0.0, "", sl));
     }
     b.bias_grad(ops, Ld, "Gdc");
     {
@@ -498,7 +513,7 @@ int build_illum_bwd(Builder& b, std::vector<Fn>& ops)
 int build_all(Plan& pl, bool dry)
 {
     Builder b(pl, dry);
-    pl.fwd.clear(); pl.pass2.clear(); pl.lossbwd.clear();
+    pl.fwd.clear(); pl.pass2.clear(); pl.lossbwd.clear(); pl.slab_seq = 0;
     CK(build_decomposition_fwd(b, pl.fwd, "x", 1));
     CK(build_illum_fwd(b, pl.fwd));
     CK(build_decomposition_fwd(b, pl.pass2, "S", 2));
@@ -550,6 +565,41 @@ int run_ops(std::vector<Fn>& ops, hipStream_t st)
     return 0;
 }
 
+int g_overlap = 1;      // ssie_debug_set_overlap: 0 = everything in launch order on the caller's stream
+
+// backward schedule with the slab reductions on the side stream:
+//   wgrad(slab b)   on st   : waits for the reduction that last read slab b, then records ev_w[b]
+//   reduce(slab b)  on side : waits for ev_w[b], records ev_r[b]
+// and st joins the side stream at the end, so everything after the call (Adam, the gradient all-reduce) sees the
+// complete gradient buffer.  Reductions stay in launch order among themselves (one side stream), which keeps the
+// two-pass accumulation into the shared decomposition-net gradients deterministic.
+int run_ops_overlapped(Plan& pl, std::vector<Fn>& ops, hipStream_t st)
+{
+    if (!g_overlap) return run_ops(ops, st);
+    if (!pl.side) {
+        if (hipStreamCreateWithFlags(&pl.side, hipStreamNonBlocking) != hipSuccess) return SSIE_E_LAUNCH;
+        for (int i = 0; i < 2; ++i)
+            if (hipEventCreateWithFlags(&pl.ev_w[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&pl.ev_r[i], hipEventDisableTiming) != hipSuccess) return SSIE_E_LAUNCH;
+    }
+    bool pending[2] = {false, false};
+    int rc = 0;
+    for (auto& f : ops) {
+        if (f.kind == K_WGRAD) {
+            if (pending[f.slab]) { hipStreamWaitEvent(st, pl.ev_r[f.slab], 0); pending[f.slab] = false; }
+            if (f(st)) { rc = SSIE_E_LAUNCH; break; }
+            hipEventRecord(pl.ev_w[f.slab], st);
+        } else if (f.kind == K_WGRAD_REDUCE) {
+            hipStreamWaitEvent(pl.side, pl.ev_w[f.slab], 0);
+            if (f(pl.side)) { rc = SSIE_E_LAUNCH; break; }
+            hipEventRecord(pl.ev_r[f.slab], pl.side);
+            pending[f.slab] = true;
+        } else if (f(st)) { rc = SSIE_E_LAUNCH; break; }
+    }
+    for (int i = 0; i < 2; ++i) if (pending[i]) hipStreamWaitEvent(st, pl.ev_r[i], 0);   // join (also on the error path)
+    return rc;
+}
+
 } // namespace
 
 // -------------------------------------------------------------------------------------------------
@@ -575,6 +625,7 @@ extern "C" void* ssie_plan_create(int N, int bands, int H, int W, const float* c
     return pl;
 }
 
+extern "C" void ssie_debug_set_overlap(int on) { g_overlap = on; }
 extern "C" void ssie_plan_destroy(void* h) { delete (Plan*)h; }
 extern "C" size_t ssie_plan_workspace_bytes(void* h) { return h ? ((Plan*)h)->ws_floats * 4 : 0; }
 extern "C" size_t ssie_plan_param_floats(void* h) { return h ? ((Plan*)h)->nparam_floats : 0; }
@@ -671,7 +722,7 @@ extern "C" int ssie_plan_loss_fwd_bwd(void* h, const float* x, const long* strid
     CK(run_ops(pl->pass2, st));
     if (with_backward) {
         if (hipMemsetAsync(pl->G, 0, pl->nparam_floats * 4, st) != hipSuccess) return SSIE_E_LAUNCH;
-        return run_ops(pl->lossbwd, st);
+        return run_ops_overlapped(*pl, pl->lossbwd, st);
     }
     // loss only: the first three ops of lossbwd are loss_direct, fft_loss, finalize (they also write cotangents)
     for (int i = 0; i < 3; ++i) { int rc = pl->lossbwd[i](st); if (rc) return SSIE_E_LAUNCH; }

@@ -42,6 +42,8 @@ def lib():
     L = C.CDLL(path)
     L.ssie_version.restype = C.c_char_p
     L.ssie_op_workspace_bytes.restype = C.c_size_t
+    if os.environ.get("SSIE_OVERLAP") is not None:      # dev switch: 0 = slab reductions in launch order on the main stream
+        L.ssie_debug_set_overlap(int(os.environ["SSIE_OVERLAP"]))
     _LIB = L
     return L
 
