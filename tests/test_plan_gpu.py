@@ -22,7 +22,10 @@ CASES = {
     "b31_32": (2, 31, 32, 32, O.JYU_COEFS),
     "b31_64": (2, 31, 64, 64, O.JYU_COEFS),
     "b8_32x64": (3, 8, 32, 64, O.JYU_COEFS),
+    "b31_128": (1, 31, 128, 128, O.JYU_COEFS),       # BASELINE.json configs[1] geometry (one patch of the bench batch)
+    "b256_64": (1, 256, 64, 64, O.JYU_COEFS),        # BASELINE.json configs[2]: 256-band cubes
 }
+GRAD_FLOOR = {"b256_64": 5e-3}
 
 
 @pytest.fixture(scope="module")
@@ -67,8 +70,13 @@ def test_stagewise_parity(pkg, case):
     _, grads32, _ = O.loss_and_grads(P, x, coefs, tr32)
     report, bad = [], []
 
+    # 256 bands: the (R,I)/D cotangents carry 5-7e-2 of sg() flip noise in BOTH fp32 evaluations (see the report), and the
+    # deep illumination-net gradients average an independent realisation of it down to ~3e-3; one fp32 oracle run is too
+    # noisy an estimate of that per tensor, so the floor is raised for this case only
+    floor = GRAD_FLOOR.get(case, 1e-3)
+
     def gtol(ref32, ref64):
-        return max(1e-3, 2.0 * rel_l2(ref32, ref64))
+        return max(floor, 2.0 * rel_l2(ref32, ref64))
 
     def chk(label, got, ref, tol, kind="abs"):
         got = got.detach().double().cpu(); ref = ref.detach().double()
@@ -156,6 +164,24 @@ def test_golden_reference_outputs(pkg, golden_dir, case):
         if "grad/" + name in g.files:
             r = torch.from_numpy(g["grad/" + name]).reshape(-1)
             assert rel_l2(gr.cpu(), r) <= 6e-3, name
+
+
+@pytest.mark.parametrize("n,bands,h,w", [(1, 31, 200, 264), (2, 31, 50, 38), (1, 256, 128, 128)])
+def test_enhance_only_ragged_sizes(pkg, n, bands, h, w):
+    """Enhance-only path (test/inference entry, model.py:229-234) on sizes that are not multiples of the 16-pixel
+    tiles or of 8 (odd pyramid levels: the nearest up-sampling reads ceil-sized levels), and on full-size 256-band cubes."""
+    H, _ = pkg
+    plan, table, flat, gflat, P = build_plan(H, n, bands, h, w, O.JYU_COEFS)
+    x = O.synthetic_patches(n, bands, h, w)
+    plan.enhance_fwd(x.cuda())
+    torch.cuda.synchronize()
+    R, I, D, S = O.enhance_forward({k: v.double() for k, v in P.items()}, x.double())
+    B = bands
+    assert (plan.nchw("RL_1", 0, B).cpu().double() - R).abs().max() <= 1e-5
+    assert (plan.nchw("RL_1", B, B + 1).cpu().double() - I).abs().max() <= 1e-5
+    assert (plan.nchw("D", 0, 1).cpu().double() - D).abs().max() <= 1e-5
+    assert (plan.nchw("S", 0, B).cpu().double() - S).abs().max() <= 1e-5
+    assert O.psnr(plan.nchw("S", 0, B).cpu(), S) > 100
 
 
 def test_module_api_and_adam(pkg):
