@@ -109,3 +109,28 @@ __device__ __forceinline__ void ssie_epilogue_full(const PT& p, const f32x16& ac
 #pragma unroll
     for (int r = 0; r < 16; ++r) ob[SSIE_EOFF(r)] = v[r];
 }
+
+// General (edge-tile) variant of the above: per-element bounds checks; arow / bcol = output-grid position of tile
+// element (row 0, column 4h).
+template <typename PT>
+__device__ __forceinline__ void ssie_epilogue_ragged(const PT& p, const f32x16& acc, size_t o0, long rowstride, long pixstride,
+                                                     float bv, int arow, int bcol)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int tr = r >> 3, tc = (r & 3) + 8 * ((r >> 2) & 1);
+        const int a = arow + tr, b = bcol + tc;
+        if (a >= p.Ho || b >= p.Wo) continue;
+        if (a * p.so + p.py >= p.Hout || b * p.so + p.px >= p.Wout) continue;
+        const size_t o = o0 + tr * rowstride + tc * pixstride;
+        float v = acc[r] + bv;
+        if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+        else if (p.act == ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+        if (p.mask_mode == MASK_RELU) v = p.mask_y[o] > 0.f ? v : 0.f;
+        else if (p.mask_mode == MASK_SIGMOID) { float y = p.mask_y[o]; v *= y * (1.f - y); }
+        if (p.out2) p.out2[o] = v;
+        if (p.addsrc) v += p.addsrc[o];
+        if (p.accumulate) v += p.out[o];
+        p.out[o] = v;
+    }
+}

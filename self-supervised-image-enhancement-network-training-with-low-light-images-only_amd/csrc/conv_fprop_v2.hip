@@ -12,6 +12,25 @@
 
 __device__ f32x4 ssie_zero_page[4];   // zero-initialised: source of padding slots
 
+// Diagnostic build only (-DSSIE_STAMP, tools/stamp_v2.py): wave 0's s_memtime spent per phase, summed per workgroup:
+// [0] start [1] barrier wait at a tile's first step [2] barrier wait at other steps [3] end [4] DMA issue [5] epilogue
+// [6] tiles [7] MFMA tap loops.  The shipped library never executes a stamp.
+#ifdef SSIE_STAMP
+__device__ unsigned long long* ssie_stamp_buf_v2 = nullptr;
+extern "C" int ssie_debug_set_stamp_buffer_v2(void* buf)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(ssie_stamp_buf_v2), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+#define ST_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t_ = __builtin_amdgcn_s_memtime(); st_[0] = st_t_;
+#define ST_ACC(k) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_[k] += t_ - st_t_; st_t_ = t_; } while (0)
+#define ST_FLUSH do { st_[3] = __builtin_amdgcn_s_memtime(); if (ssie_stamp_buf_v2 && threadIdx.x == 0) \
+    for (int k_ = 0; k_ < 8; ++k_) ssie_stamp_buf_v2[(size_t)blockIdx.x * 8 + k_] = st_[k_]; } while (0)
+#else
+#define ST_DECL
+#define ST_ACC(k)
+#define ST_FLUSH
+#endif
+
 #define GLDS16(gptr, lptr)                                                                             \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),            \
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
@@ -31,12 +50,18 @@ __device__ __forceinline__ const f32x4* ssie_virtual_addr(const SrcSel& s, bool 
     return ok ? (const f32x4*)(s.ptr + off) : (const f32x4*)ssie_zero_page;
 }
 
-template <int NT, int NA2>
-__global__ __launch_bounds__(512, 2) void conv_fprop_v2_kernel(const ConvParams p)
+// NW = waves per workgroup: 8 (one 512-thread workgroup per CU, 64- or 32-channel tiles) or 4 (TWO independent
+// 256-thread workgroups per CU, 32-channel tiles, ~78 KiB LDS each): the two workgroups drift out of phase, so the DMA
+// issue / epilogue / barrier phases of one run underneath the MFMA phase of the other (tools/stamp_v2.py: those phases
+// are ~20 % of a lock-stepped 8-wave workgroup's time)
+template <int NT, int NA2, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void conv_fprop_v2_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     constexpr int BN = 32 * NT, TH = 16;
-    constexpr int MT = (NT == 1) ? 1 : 2;
+    constexpr int NTHR = 64 * NW;
+    constexpr int WM = (NT == 2) ? NW / 2 : NW;     // waves along M; the 16 x 16 tile has 8 M-tiles of 2 x 16 positions
+    constexpr int MT = 8 / WM;
     constexpr int BSZ = SSIE_TG * 4 * BN;           // float4 per B buffer
     const int HP = p.hp_h * p.hp_w, HP4 = HP * 4;
     f32x4* As0 = (f32x4*)smem_f;                    // [2][HP4]
@@ -49,7 +74,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_v2_kernel(const ConvParams 
     const int wn = (NT == 1) ? 0 : (wave & 1);
     const int wm = (NT == 1) ? wave : (wave >> 1);
 
-    for (int t = tid; t < p.ntaps; t += 512)
+    for (int t = tid; t < p.ntaps; t += NTHR)
         tapoff[t] = ((int)p.tap_dy[t] - p.min_dy) * p.hp_w + ((int)p.tap_dx[t] - p.min_dx);
 
     int pixbase[MT];
@@ -62,11 +87,11 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_v2_kernel(const ConvParams 
     const int nsteps = p.nchunks * ngroups;
     const int total_tiles = p.N * p.tiles_y * p.tiles_x * p.co_blocks;
 
-    // this lane's halo slots: LDS slot id = i*512 + tid (linear), it holds channel quad j = (id&3) ^ swz(pixel)
+    // this lane's halo slots: LDS slot id = i*NTHR + tid (linear), it holds channel quad j = (id&3) ^ swz(pixel)
     int ahy[NA2], ahx[NA2], aj[NA2];
 #pragma unroll
     for (int i = 0; i < NA2; ++i) {
-        const int id = min(tid + i * 512, HP4 - 1);
+        const int id = min(tid + i * NTHR, HP4 - 1);
         const int pix = id >> 2;
         ahy[i] = pix / p.hp_w; ahx[i] = pix - ahy[i] * p.hp_w; aj[i] = (id & 3) ^ ssie_swz(pix);
     }
@@ -88,10 +113,10 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_v2_kernel(const ConvParams 
             const int vy0_ = (A0_) + p.min_dy, vx0_ = (B0_) + p.min_dx;                                       \
             f32x4* abuf_ = As0 + (ABUF) * HP4;                                                                \
             _Pragma("unroll") for (int i_ = 0; i_ < NA2; ++i_) {                                              \
-                if (tid + i_ * 512 < HP4) {                                                                   \
+                if (tid + i_ * NTHR < HP4) {                                                                  \
                     const f32x4* g_ = ssie_virtual_addr(s_, up_, (N_), vy0_ + ahy[i_], vx0_ + ahx[i_], p.Hv, p.Wv, \
                                                         (CHUNK) * SSIE_CK + 4 * aj[i_] - s_.cbeg);            \
-                    GLDS16(g_, abuf_ + i_ * 512 + wave * 64);                                                 \
+                    GLDS16(g_, abuf_ + i_ * NTHR + wave * 64);                                                \
                 }                                                                                             \
             }                                                                                                 \
         }                                                                                                     \
@@ -99,7 +124,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_v2_kernel(const ConvParams 
         const int pieces_ = min(SSIE_TG, p.ntaps - t0_) * 4 * BN / 64;                                        \
         const f32x4* wsrc_ = (const f32x4*)p.wpacked + ((size_t)((CHUNK) * p.ntaps + t0_) * 4) * p.Cout_pad + (CO0_); \
         f32x4* bbuf_ = Bs0 + (BUF) * BSZ;                                                                     \
-        for (int q_ = wave; q_ < pieces_; q_ += 8) {                                                          \
+        for (int q_ = wave; q_ < pieces_; q_ += NW) {                                                         \
             const int slot_ = q_ * 64 + lane;                                                                 \
             GLDS16(wsrc_ + (size_t)(slot_ / BN) * p.Cout_pad + (slot_ % BN), bbuf_ + q_ * 64);                \
         }                                                                                                     \
@@ -113,6 +138,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_v2_kernel(const ConvParams 
     int a_cur = 0;          // A buffer holding the halo tile of the step about to be computed
     V2_PREFETCH(0, 0, n, a0, b0, co0, 0, 0)
     int fetched = 0x7fffffff;
+    ST_DECL
     // The two waves of a SIMD (w and w+4) run the same program; issuing the next step's DMA (address VALU work) at
     // the same moment would leave the SIMD's MFMA pipe idle.  Waves 4-7 therefore issue it in the middle of their
     // tap loop while waves 0-3 issue it up front.
@@ -140,8 +166,10 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_v2_kernel(const ConvParams 
             }
             // ONE barrier per step: my DMA for this step has landed (vmcnt) and every wave has finished reading the
             // other buffer (previous step), which the prefetch below overwrites
+            ST_ACC(5);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            ST_ACC(step == 0 ? 1 : 2);
             if (step == (nsteps > 1 ? 1 : 0)) {
                 ntile = *s_next;
                 if (ntile < total_tiles) V2_DECODE(ntile, nn, na0, nb0, nco0)
@@ -156,6 +184,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_v2_kernel(const ConvParams 
                 else if (ntile < total_tiles) V2_PREFETCH(0, 0, nn, na0, nb0, nco0, buf ^ 1, a_nxt)       \
             }
             if (!late_prefetch) V2_ISSUE_NEXT
+            ST_ACC(4);
 
             const f32x4* As = As0 + a_cur * HP4;
             const f32x4* Bs = Bs0 + buf * BSZ;
@@ -194,6 +223,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_v2_kernel(const ConvParams 
             if (tid == 0 && step == 0 && nsteps > 1 && p.tile_counter)
                 fetched = (int)gridDim.x + atomicAdd(p.tile_counter, 1);
             chunk = nchunk; g = ng; a_cur = a_nxt;
+            ST_ACC(7);
         }
 
         // epilogue (identical mapping to the v1 kernel; TH = 16 so M-tile mt covers tile rows 2*mt, 2*mt+1)
@@ -230,13 +260,18 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_v2_kernel(const ConvParams 
             }
         }
         n = nn; a0 = na0; b0 = nb0; co0 = nco0; tile = ntile;
+#ifdef SSIE_STAMP
+        st_[6] += 1;
+#endif
     }
+    ST_ACC(5);
+    ST_FLUSH;
 #undef V2_PREFETCH
 #undef V2_DECODE
 }
 
-#define INST_V2(NT, NA2) template __global__ void conv_fprop_v2_kernel<NT, NA2>(const ConvParams);
-INST_V2(1, 3) INST_V2(1, 5) INST_V2(2, 3) INST_V2(2, 5)
+#define INST_V2(NT, NA2, NW) template __global__ void conv_fprop_v2_kernel<NT, NA2, NW>(const ConvParams);
+INST_V2(1, 3, 8) INST_V2(1, 5, 8) INST_V2(2, 3, 8) INST_V2(2, 5, 8) INST_V2(1, 6, 4)
 
 size_t ssie_fprop_v2_lds_bytes(const ConvParams& p, int nt)
 {
@@ -252,22 +287,39 @@ bool ssie_fprop_v2_ok(const ConvParams& p)
     return na2 <= 5 && ssie_fprop_v2_lds_bytes(p, nt) <= 160 * 1024;
 }
 
-template <int NT, int NA2>
+static int g_v2_split = 1;      // ssie_debug_set_fprop_v2_split: 0 = always one 8-wave workgroup per CU
+extern "C" void ssie_debug_set_fprop_v2_split(int on) { g_v2_split = on; }
+
+template <int NT, int NA2, int NW>
 static int launch_v2_t(const ConvParams& p, size_t lds, hipStream_t st)
 {
     static bool set = false;
-    if (!set) { hipFuncSetAttribute((const void*)conv_fprop_v2_kernel<NT, NA2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    if (!set) { hipFuncSetAttribute((const void*)conv_fprop_v2_kernel<NT, NA2, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
     const size_t tiles = (size_t)p.N * p.tiles_y * p.tiles_x * p.co_blocks;
-    const size_t wgs = tiles < 256 ? tiles : 256;
-    hipLaunchKernelGGL((conv_fprop_v2_kernel<NT, NA2>), dim3((unsigned)wgs), dim3(512), lds, st, p);
+    const size_t cap = NW == 8 ? 256 : 512;
+    const size_t wgs = tiles < cap ? tiles : cap;
+    hipLaunchKernelGGL((conv_fprop_v2_kernel<NT, NA2, NW>), dim3((unsigned)wgs), dim3(64 * NW), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : 18;
 }
 
 int ssie_launch_fprop_v2(const ConvParams& p, hipStream_t st)
 {
     const int nt = (p.Cout_pad % 64 == 0) ? 2 : 1;
+    // 32-channel layers: two 4-wave workgroups per CU (both must fit the LDS, and there must be enough tiles to fill
+    // them).  Measured: +7 % over one 8-wave workgroup there; splitting a 64-channel tile into two 32-channel
+    // workgroups instead costs 6 % (the halo tile is fetched twice).
+    {
+        const size_t lds1 = ssie_fprop_v2_lds_bytes(p, 1);
+        const int na4 = (p.hp_h * p.hp_w * 4 + 255) / 256;
+        const size_t tiles32 = (size_t)p.N * p.tiles_y * p.tiles_x * (p.Cout_pad / 32);
+        if (g_v2_split && nt == 1 && 2 * (lds1 + 256) <= 160 * 1024 && na4 <= 6 && tiles32 >= 1024) {
+            ConvParams q = p;
+            q.co_blocks = p.Cout_pad / 32;
+            return launch_v2_t<1, 6, 4>(q, lds1, st);
+        }
+    }
     const int na2 = (p.hp_h * p.hp_w * 4 + 511) / 512;
     const size_t lds = ssie_fprop_v2_lds_bytes(p, nt);
-    if (nt == 2) return na2 <= 3 ? launch_v2_t<2, 3>(p, lds, st) : launch_v2_t<2, 5>(p, lds, st);
-    return na2 <= 3 ? launch_v2_t<1, 3>(p, lds, st) : launch_v2_t<1, 5>(p, lds, st);
+    if (nt == 2) return na2 <= 3 ? launch_v2_t<2, 3, 8>(p, lds, st) : launch_v2_t<2, 5, 8>(p, lds, st);
+    return na2 <= 3 ? launch_v2_t<1, 3, 8>(p, lds, st) : launch_v2_t<1, 5, 8>(p, lds, st);
 }

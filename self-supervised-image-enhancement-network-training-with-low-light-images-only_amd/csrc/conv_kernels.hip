@@ -236,24 +236,8 @@ __global__ __launch_bounds__(256, ((NA <= 3 && TH == 8) ? 3 : 2)) void conv_fpro
                 const int mt = wm * MT + m;
                 const int arow = a0 + 2 * mt, bcol = b0 + 4 * h;
                 const size_t o0 = ((size_t)(n * p.Hout + arow * p.so + p.py) * p.Wout + bcol * p.so + p.px) * p.out_cstride + p.out_coff + co;
-                if (full) { ssie_epilogue_full(p, acc[m], o0, rowstride, pixstride, bv); continue; }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int tr = r >> 3, tc = (r & 3) + 8 * ((r >> 2) & 1);
-                    const int a = arow + tr, b = bcol + tc;
-                    if (a >= p.Ho || b >= p.Wo) continue;
-                    if (a * p.so + p.py >= p.Hout || b * p.so + p.px >= p.Wout) continue;
-                    const size_t o = o0 + tr * rowstride + tc * pixstride;
-                    float v = acc[m][r] + bv;
-                    if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (p.act == ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
-                    if (p.mask_mode == MASK_RELU) v = p.mask_y[o] > 0.f ? v : 0.f;
-                    else if (p.mask_mode == MASK_SIGMOID) { float y = p.mask_y[o]; v *= y * (1.f - y); }
-                    if (p.out2) p.out2[o] = v;
-                    if (p.addsrc) v += p.addsrc[o];
-                    if (p.accumulate) v += p.out[o];
-                    p.out[o] = v;
-                }
+                if (full) ssie_epilogue_full(p, acc[m], o0, rowstride, pixstride, bv);
+                else ssie_epilogue_ragged(p, acc[m], o0, rowstride, pixstride, bv, arow, bcol);
             }
         }
         n = nn; a0 = na0; b0 = nb0; co0 = nco0; tile = ntile;
@@ -335,6 +319,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     const int bcol = tid % COB, brow = tid / COB;
     float bsum = 0.f;
 
+#ifdef SSIE_STAMP
+    unsigned long long ws_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ws_t_ = __builtin_amdgcn_s_memtime(); ws_[0] = ws_t_; ws_[4] = __builtin_amdgcn_s_memrealtime();
+#define WST(k) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); ws_[k] += t_ - ws_t_; ws_t_ = t_; } while (0)
+#else
+#define WST(k)
+#endif
     for (int tile = tile_beg; tile < tile_end; ++tile) {
         int tt = tile;
         const int tx = tt % p.tiles_x; tt /= p.tiles_x;
@@ -343,6 +333,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         const int a0 = ty * p.th, b0 = tx * SSIE_TW;
         const int vy0 = a0 * p.si + gmin_dy, vx0 = b0 * p.si + p.min_dx;
         __syncthreads();
+        WST(2);
         // staging in batches of UB independent 16-byte loads per thread so the global latency is paid once per
         // batch, not once per element
         constexpr int UB = 6;
@@ -386,10 +377,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
                 if (id < PT * CO4) *(f32x4*)(Gs + (id / CO4) * COB + 4 * (id % CO4)) = r[u];
             }
         }
+        WST(1);
         __syncthreads();
+        WST(2);
         if (do_bias)
             for (int px = brow; px < PT; px += BROWS) bsum += Gs[px * COB + bcol];
         // MFMA K loop over position pairs (this wave's share: kp = wsub, wsub + WSPLIT, ...)
+        // (a register-ping-pong software pipeline of this loop cuts its cycles by 30 % in isolation but the clock and the
+        //  co-resident workgroup's staging give all of it back: slower by 2-4 % in wall time, tools/stamp_wgrad.py)
         const int npair = PT / 2;
         for (int kp = wsub; kp < npair; kp += WSPLIT) {
             const int pix = 2 * kp + h;
@@ -401,6 +396,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
                 acc[u] = MFMA32(a, b, acc[u]);
             }
         }
+        WST(7);
+#ifdef SSIE_STAMP
+        ws_[6] += 1;
+#endif
     }
 
     if (do_bias) {
@@ -447,6 +446,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
             dst[(size_t)i * p.co_pad] = acc[u][r];
         }
     }
+#ifdef SSIE_STAMP
+    WST(5);
+    ws_[3] = __builtin_amdgcn_s_memtime(); ws_[4] = __builtin_amdgcn_s_memrealtime() - ws_[4];
+    if (ssie_stamp_buf && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+        for (int k_ = 0; k_ < 8; ++k_) ssie_stamp_buf[(size_t)blockIdx.x * 8 + k_] = ws_[k_];
+#endif
+#undef WST
 }
 
 #define INST_WGRAD(CI, CO, NU) template __global__ void conv_wgrad_kernel<CI, CO, NU>(const WgradParams);

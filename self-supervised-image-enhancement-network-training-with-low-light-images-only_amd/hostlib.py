@@ -34,7 +34,9 @@ def lib():
     if _LIB is not None:
         return _LIB
     path = _build.LIB
-    if not _build.up_to_date():
+    if os.environ.get("SSIE_HIP_LIB"):       # dev switch for A/B runs of two builds inside one GPU session
+        path = os.environ["SSIE_HIP_LIB"]
+    elif not _build.up_to_date():
         if _build.hipcc() is None and not os.path.exists(path):
             raise SsieError("libssie_hip.so is missing and hipcc is unavailable; run __graft_entry__.build()")
         if _build.hipcc() is not None:
@@ -44,6 +46,8 @@ def lib():
     L.ssie_op_workspace_bytes.restype = C.c_size_t
     if os.environ.get("SSIE_OVERLAP") is not None:      # dev switch: 0 = slab reductions in launch order on the main stream
         L.ssie_debug_set_overlap(int(os.environ["SSIE_OVERLAP"]))
+    if os.environ.get("SSIE_V2_SPLIT") is not None:     # dev switch: 0 = never split a CU between two 4-wave workgroups
+        L.ssie_debug_set_fprop_v2_split(int(os.environ["SSIE_V2_SPLIT"]))
     _LIB = L
     return L
 
