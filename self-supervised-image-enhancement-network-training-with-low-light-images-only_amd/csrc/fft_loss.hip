@@ -12,36 +12,72 @@
 #include "loss_kernels.h"
 #include <math.h>
 
-#define FFT_THREADS 512
+#define FFT_THREADS 1024
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
-// one radix-2 pass over `lines` independent lines of length n (element stride es, line stride ls)
-template <bool INVERSE>
-__device__ __forceinline__ void fft_pass(float2* z, const float2* tw, int twM, int n, int logn, int lines, int es, int ls, int tid)
+// R consecutive radix-2 stages (st0 .. st0+R-1) of `lines` independent length-n transforms, done in registers: a thread
+// gathers the 2^R elements that only interact with each other during those stages, runs the R butterfly levels on them
+// and writes them back - one LDS round trip and one barrier per R stages instead of per stage.  The butterflies, their
+// twiddles and their order per element are exactly those of the plain radix-2 schedule (forward: decimation in frequency,
+// natural in / bit-reversed out; inverse: decimation in time on the bit-reversed layout), so results are unchanged.
+// Lanes run over LINES first: row passes then touch addresses (W+1)*8 B apart and column passes 8 B apart, both
+// bank-conflict free, and all lanes of a wave share each twiddle (LDS broadcast).
+template <bool INVERSE, int R>
+__device__ __forceinline__ void fft_block(float2* z, const float2* tw, int logM, int n, int logn, int lines, int loglines,
+                                          int es, int ls, int tid, int st0)
 {
-    const int half = n >> 1;
-    for (int st = 0; st < logn; ++st) {
-        const int s = INVERSE ? (1 << st) : (half >> st);
-        const int tstep = twM / (2 * s);
-        for (int id = tid; id < lines * half; id += FFT_THREADS) {
-            const int line = id / half, k = id - line * half;
-            const int blk = k / s, j = k - blk * s;
-            float2* p0 = z + line * ls + (blk * 2 * s + j) * es;
-            float2* p1 = p0 + s * es;
-            float2 w = tw[j * tstep];
-            float2 a = *p0, b = *p1;
-            if (INVERSE) {
-                w.y = -w.y;
-                b = cmul(b, w);
-                *p0 = make_float2(a.x + b.x, a.y + b.y);
-                *p1 = make_float2(a.x - b.x, a.y - b.y);
-            } else {
-                *p0 = make_float2(a.x + b.x, a.y + b.y);
-                *p1 = cmul(make_float2(a.x - b.x, a.y - b.y), w);
+    constexpr int RR = 1 << R;
+    const int lo = INVERSE ? st0 : logn - st0 - R;          // lowest of the R index bits handled here
+    const int items = lines * (n >> R);
+    for (int id = tid; id < items; id += FFT_THREADS) {
+        const int line = id & (lines - 1), g = id >> loglines;
+        const int base = ((g >> lo) << (lo + R)) | (g & ((1 << lo) - 1));
+        float2* zl = z + line * ls;
+        float2 v[RR];
+#pragma unroll
+        for (int r = 0; r < RR; ++r) v[r] = zl[(base + (r << lo)) * es];
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            const int bit = INVERSE ? t : R - 1 - t;
+            const int s = 1 << (lo + bit);
+            const int tshift = logM - (lo + bit + 1);       // twiddle index step = M / (2 s)
+#pragma unroll
+            for (int r0 = 0; r0 < RR; ++r0) {
+                if (r0 & (1 << bit)) continue;
+                const int r1 = r0 | (1 << bit);
+                const int j = (base + (r0 << lo)) & (s - 1);
+                float2 w = tw[j << tshift];
+                const float2 a = v[r0], b = v[r1];
+                if (INVERSE) {
+                    w.y = -w.y;
+                    const float2 bw = cmul(b, w);
+                    v[r0] = make_float2(a.x + bw.x, a.y + bw.y);
+                    v[r1] = make_float2(a.x - bw.x, a.y - bw.y);
+                } else {
+                    v[r0] = make_float2(a.x + b.x, a.y + b.y);
+                    v[r1] = cmul(make_float2(a.x - b.x, a.y - b.y), w);
+                }
             }
         }
-        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RR; ++r) zl[(base + (r << lo)) * es] = v[r];
+    }
+    __syncthreads();
+}
+
+// all log2(n) stages of `lines` transforms (element stride es, line stride ls), four stages per LDS round trip
+template <bool INVERSE>
+__device__ __forceinline__ void fft_pass(float2* z, const float2* tw, int logM, int n, int logn, int lines, int loglines,
+                                         int es, int ls, int tid)
+{
+    int st = 0;
+    for (; logn - st >= 4; st += 4) fft_block<INVERSE, 4>(z, tw, logM, n, logn, lines, loglines, es, ls, tid, st);
+    switch (logn - st) {
+    case 3: fft_block<INVERSE, 3>(z, tw, logM, n, logn, lines, loglines, es, ls, tid, st); break;
+    case 2: fft_block<INVERSE, 2>(z, tw, logM, n, logn, lines, loglines, es, ls, tid, st); break;
+    case 1: fft_block<INVERSE, 1>(z, tw, logM, n, logn, lines, loglines, es, ls, tid, st); break;
+    default: break;
     }
 }
 
@@ -69,8 +105,9 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_loss_kernel(const FftParams p
         z[h * LS + w] = make_float2(p.x[(base + id) * p.x_cs + c], p.S[(base + id) * p.s_cs + c]);
     }
     __syncthreads();
-    fft_pass<false>(z, tw, M, W, p.logW, H, 1, LS, tid);      // rows
-    fft_pass<false>(z, tw, M, H, p.logH, W, LS, 1, tid);      // columns
+    const int logM = p.logH > p.logW ? p.logH : p.logW;
+    fft_pass<false>(z, tw, logM, W, p.logW, H, p.logH, 1, LS, tid);      // rows
+    fft_pass<false>(z, tw, logM, H, p.logH, W, p.logW, LS, 1, tid);      // columns
 
     // pointwise: loss and g_Z per conjugate pair {k, -k}
     float lsum = 0.f;
@@ -95,8 +132,8 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_loss_kernel(const FftParams p
         if (id != idm) z[pm] = Gm;
     }
     __syncthreads();
-    fft_pass<true>(z, tw, M, H, p.logH, W, LS, 1, tid);       // columns (bit-reversed in, natural out)
-    fft_pass<true>(z, tw, M, W, p.logW, H, 1, LS, tid);       // rows
+    fft_pass<true>(z, tw, logM, H, p.logH, W, p.logW, LS, 1, tid);       // columns (bit-reversed in, natural out)
+    fft_pass<true>(z, tw, logM, W, p.logW, H, p.logH, 1, LS, tid);       // rows
     for (int id = tid; id < H * W; id += FFT_THREADS) {
         const int h = id / W, w = id - h * W;
         p.gS[(base + id) * p.s_cs + c] += z[h * LS + w].x;
