@@ -126,7 +126,8 @@ def main():
         # comes from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (profiles/)
         traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))["kernels"]
+            import glob
+            tj = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))[-1]))["kernels"]
             cand = [v["hbm_bytes_per_launch"] * v["launches_sampled"] for k, v in tj.items() if k.startswith("conv_fprop")]
             nl = sum(v["launches_sampled"] for k, v in tj.items() if k.startswith("conv_fprop"))
             traffic = int(sum(cand) / nl) if nl else None
