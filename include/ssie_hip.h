@@ -128,6 +128,9 @@ int ssie_plan_bind(void* plan, void* workspace, size_t ws_bytes, float* params, 
 /* LowLightEnhance.forward (model.py:229-234): x is the logical (N,bands,H,W) fp32 tensor with element
  * strides strides4 = {sN, sC, sH, sW} (channels_last or contiguous alike) */
 int ssie_plan_enhance_fwd(void* plan, const float* x, const long* strides4, void* stream);
+/* same outputs, computed with bf16 storage + bf16 MFMA (fp32 accumulate): the mixed-precision inference path of
+ * BASELINE.json configs[4]; no counterpart in the reference (fp32 only, model.py:229-234) */
+int ssie_plan_enhance_fwd_bf16(void* plan, const float* x, const long* strides4, void* stream);
 
 /* compute_loss (+ loss.backward() when with_backward != 0): model.py:544-575, :315.  Writes "scalars";
  * with_backward also zeroes and fills the flat gradient buffer (zero_grad, model.py:313).
@@ -144,6 +147,11 @@ int ssie_plan_profile_step(void* plan, const float* x, const long* strides4, voi
 /* dev tool: per-launch device ms / algorithmic FLOPs / kind in launch order; returns the op count (or -error) */
 int ssie_plan_profile_ops(void* plan, const float* x, const long* strides4, void* stream,
                           double* ms, double* flops, int* kinds, int cap, char* tags, int tags_cap);
+/* dev tool: per-launch timing of one op list; which = 0 fp32 enhance forward, 1 = bf16 enhance forward */
+int ssie_plan_profile_list(void* plan, const float* x, const long* strides4, void* stream, int which,
+                           double* ms, double* flops, int* kinds, int cap, char* tags, int tags_cap);
+/* launches per op list: {enhance forward, second decomposition pass, loss + backward} (dev tools) */
+int ssie_plan_num_ops(void* plan, int* counts3);
 
 /* torch.optim.Adam.step with default hyper-parameters (model.py:213, :316) over flat buffers;
  * grads are multiplied by grad_scale first (1/world_size after an all-reduce-sum) */

@@ -1,0 +1,275 @@
+// conv_fprop_bf16_kernel: the enhance-only (inference) convolution with bf16 storage and bf16 MFMA, fp32 accumulate
+// (BASELINE.json configs[4]: "bf16 mixed precision + full-resolution inference").
+//
+// Same implicit-GEMM structure as conv_fprop_v2_kernel (one 512-thread workgroup per CU, LDS double-buffered by
+// global->LDS DMA, one barrier per step, persistent workgroups on a dynamic tile queue), with these differences:
+//   * activations are bf16 NHWC in memory (channel stride a multiple of 8); a K-chunk is 32 channels, so a pixel of the
+//     halo tile is still 64 B = four 16-byte slots (slot j = channels 8j .. 8j+7) and the DMA / swizzle code is unchanged
+//   * one v_mfma_f32_32x32x16_bf16 consumes a 16-channel half chunk: lane (i, h) feeds slot 2*sc + h of pixel / column i
+//   * packed weights: [chunk32][tap][slot][Cout_pad][8 bf16] - byte-for-byte the fp32 pack's shape
+//   * the input stride may be 2 (tile of 8 x 16 positions) - the fp32 v2 kernel is stride-1 only
+//   * epilogue: bias + ReLU / sigmoid, optional bf16 skip-add, output as bf16 or fp32, optional second (bf16) copy
+// Accumulation order per output: channels ascending within a tap, taps in list order within a chunk - like the fp32 path.
+#include "conv_device.h"
+
+__device__ f32x4 ssie_zero_page_h[4];   // zero-initialised: source of padding slots
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, (a)), __builtin_bit_cast(bf16x8_t, (b)), (c), 0, 0, 0)
+
+#define GLDS16(gptr, lptr)                                                                             \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),            \
+                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+__device__ __forceinline__ unsigned short ssie_f2bf(float f)        // round to nearest even
+{
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float ssie_bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+
+// source address of 8 consecutive bf16 channels of virtual pixel (n, vy, vx), or the zero page
+__device__ __forceinline__ const f32x4* ssie_virtual_addr_h(const SrcSel& s, bool up, int n, int vy, int vx, int Hv, int Wv, int c)
+{
+    const bool ok = (unsigned)vy < (unsigned)Hv && (unsigned)vx < (unsigned)Wv && c < s.C;
+    int y = vy, x = vx;
+    if (up) {
+        const int cy = min(max(vy, 0), Hv - 1), cx = min(max(vx, 0), Wv - 1);
+        y = min((int)floorf((float)cy * s.sy), s.Hs - 1);
+        x = min((int)floorf((float)cx * s.sx), s.Ws - 1);
+    }
+    const unsigned off = (unsigned)((n * s.Hs + y) * s.Ws + x) * (unsigned)s.cstride + (unsigned)(s.coff + c);
+    return ok ? (const f32x4*)((const unsigned short*)s.ptr + off) : (const f32x4*)ssie_zero_page_h;
+}
+
+#define HOFF(r) ((long)((r) >> 3) * rowstride + (long)(((r) & 3) + 8 * (((r) >> 2) & 1)) * pixstride)
+// one 32 x 32 accumulator tile -> memory; `full` = all 2 x 16 positions lie inside the output
+__device__ __forceinline__ void ssie_epilogue_h(const ConvParams& p, const f32x16& acc, size_t o0, long rowstride, long pixstride, float bv,
+                                                bool full, int arow, int bcol)
+{
+    float v[16];
+    bool ok[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int a = arow + (r >> 3), b = bcol + (r & 3) + 8 * ((r >> 2) & 1);
+        ok[r] = full || (a < p.Ho && b < p.Wo && a * p.so + p.py < p.Hout && b * p.so + p.px < p.Wout);
+        float t = acc[r] + bv;
+        if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
+        else if (p.act == ACT_SIGMOID) t = 1.f / (1.f + expf(-t));
+        v[r] = t;
+    }
+    if (p.out2) {
+        unsigned short* o2 = (unsigned short*)p.out2 + o0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) if (ok[r]) o2[HOFF(r)] = ssie_f2bf(v[r]);
+    }
+    if (p.addsrc) {
+        const unsigned short* ap = (const unsigned short*)p.addsrc + o0;
+        unsigned short a[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = ok[r] ? ap[HOFF(r)] : (unsigned short)0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += ssie_bf2f(a[r]);
+    }
+    if (p.out_bf16) {
+        unsigned short* ob = (unsigned short*)p.out + o0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) if (ok[r]) ob[HOFF(r)] = ssie_f2bf(v[r]);
+    } else {
+        float* ob = p.out + o0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) if (ok[r]) ob[HOFF(r)] = v[r];
+    }
+}
+
+template <int NT, int NA2, int TH>
+__global__ __launch_bounds__(512, 2) void conv_fprop_bf16_kernel(const ConvParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    constexpr int NW = 8, NTHR = 64 * NW, CKH = 32;
+    constexpr int BN = 32 * NT;
+    constexpr int WM = (NT == 2) ? NW / 2 : NW;     // waves along M; a TH x 16 tile has TH/2 M-tiles of 2 x 16 positions
+    constexpr int MT = (TH / 2) / WM;
+    static_assert(MT >= 1, "tile too small for the wave grid");
+    constexpr int BSZ = SSIE_TG * 4 * BN;           // 16-byte slots per B buffer
+    const int HP = p.hp_h * p.hp_w, HP4 = HP * 4;
+    f32x4* As0 = (f32x4*)smem_f;                    // [2][HP4]
+    f32x4* Bs0 = As0 + 2 * HP4;                     // [2][BSZ]
+    int* tapoff = (int*)(Bs0 + 2 * BSZ);
+    int* s_next = tapoff + SSIE_MAX_TAPS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, li = lane & 31;
+    const int wn = (NT == 1) ? 0 : (wave & 1);
+    const int wm = (NT == 1) ? wave : (wave >> 1);
+
+    for (int t = tid; t < p.ntaps; t += NTHR)
+        tapoff[t] = ((int)p.tap_dy[t] - p.min_dy) * p.hp_w + ((int)p.tap_dx[t] - p.min_dx);
+
+    int pixbase[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int mt = wm * MT + m;
+        pixbase[m] = (2 * mt + (li >> 4)) * p.si * p.hp_w + (li & 15) * p.si;
+    }
+    const int ngroups = (p.ntaps + SSIE_TG - 1) / SSIE_TG;
+    const int nsteps = p.nchunks * ngroups;
+    const int total_tiles = p.N * p.tiles_y * p.tiles_x * p.co_blocks;
+
+    // this lane's halo slots: LDS slot id = i*NTHR + tid (linear), it holds channel octet j = (id&3) ^ swz(pixel)
+    int ahy[NA2], ahx[NA2], aj[NA2];
+#pragma unroll
+    for (int i = 0; i < NA2; ++i) {
+        const int id = min(tid + i * NTHR, HP4 - 1);
+        const int pix = id >> 2;
+        ahy[i] = pix / p.hp_w; ahx[i] = pix - ahy[i] * p.hp_w; aj[i] = (id & 3) ^ ssie_swz(pix);
+    }
+
+#define H_DECODE(T, N_, A0_, B0_, CO0_)                                                   \
+    {                                                                                     \
+        int q_ = (T);                                                                     \
+        CO0_ = (q_ % p.co_blocks) * BN; q_ /= p.co_blocks;                                \
+        B0_ = (q_ % p.tiles_x) * SSIE_TW; q_ /= p.tiles_x;                                \
+        A0_ = (q_ % p.tiles_y) * TH; N_ = q_ / p.tiles_y;                                 \
+    }
+#define H_PREFETCH(CHUNK, G, N_, A0_, B0_, CO0_, BUF, ABUF)                                                   \
+    {                                                                                                         \
+        if ((G) == 0) {                                                                                       \
+            const SrcSel s_ = ssie_pick_src(p, (CHUNK) * CKH);                                                \
+            const bool up_ = s_.sy != 1.f || s_.sx != 1.f;                                                    \
+            const int vy0_ = (A0_) * p.si + p.min_dy, vx0_ = (B0_) * p.si + p.min_dx;                         \
+            f32x4* abuf_ = As0 + (ABUF) * HP4;                                                                \
+            _Pragma("unroll") for (int i_ = 0; i_ < NA2; ++i_) {                                              \
+                if (tid + i_ * NTHR < HP4) {                                                                  \
+                    const f32x4* g_ = ssie_virtual_addr_h(s_, up_, (N_), vy0_ + ahy[i_], vx0_ + ahx[i_], p.Hv, p.Wv, \
+                                                          (CHUNK) * CKH + 8 * aj[i_] - s_.cbeg);              \
+                    GLDS16(g_, abuf_ + i_ * NTHR + wave * 64);                                                \
+                }                                                                                             \
+            }                                                                                                 \
+        }                                                                                                     \
+        const int t0_ = (G) * SSIE_TG;                                                                        \
+        const int pieces_ = min(SSIE_TG, p.ntaps - t0_) * 4 * BN / 64;                                        \
+        const f32x4* wsrc_ = (const f32x4*)p.wpacked + ((size_t)((CHUNK) * p.ntaps + t0_) * 4) * p.Cout_pad + (CO0_); \
+        f32x4* bbuf_ = Bs0 + (BUF) * BSZ;                                                                     \
+        for (int q_ = wave; q_ < pieces_; q_ += NW) {                                                         \
+            const int slot_ = q_ * 64 + lane;                                                                 \
+            GLDS16(wsrc_ + (size_t)(slot_ / BN) * p.Cout_pad + (slot_ % BN), bbuf_ + q_ * 64);                \
+        }                                                                                                     \
+    }
+
+    int tile = blockIdx.x;
+    if (tile >= total_tiles) return;
+    int n, a0, b0, co0;
+    H_DECODE(tile, n, a0, b0, co0)
+    int gstep = 0;
+    int a_cur = 0;
+    H_PREFETCH(0, 0, n, a0, b0, co0, 0, 0)
+    int fetched = 0x7fffffff;
+
+    while (tile < total_tiles) {
+        f32x16 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        int ntile = 0x7fffffff;
+        int nn = n, na0 = a0, nb0 = b0, nco0 = co0;
+
+        int chunk = 0, g = 0;
+        for (int step = 0; step < nsteps; ++step, ++gstep) {
+            const int buf = gstep & 1;
+            const int t0 = g * SSIE_TG;
+            const int tg = min(SSIE_TG, p.ntaps - t0);
+            if (tid == 0) {
+                if (nsteps == 1 || !p.tile_counter) {
+                    if (step == 0) *s_next = p.tile_counter ? (int)gridDim.x + atomicAdd(p.tile_counter, 1) : tile + (int)gridDim.x;
+                } else if (step == 1) *s_next = fetched;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (step == (nsteps > 1 ? 1 : 0)) {
+                ntile = *s_next;
+                if (ntile < total_tiles) H_DECODE(ntile, nn, na0, nb0, nco0)
+            }
+            int nchunk = chunk, ng = g + 1;
+            if (ng == ngroups) { ng = 0; ++nchunk; }
+            const bool more = step + 1 < nsteps;
+            const int a_nxt = ((more ? ng : 0) == 0) ? (a_cur ^ 1) : a_cur;
+            if (more) H_PREFETCH(nchunk, ng, n, a0, b0, co0, buf ^ 1, a_nxt)
+            else if (ntile < total_tiles) H_PREFETCH(0, 0, nn, na0, nb0, nco0, buf ^ 1, a_nxt)
+
+            const f32x4* As = As0 + a_cur * HP4;
+            const f32x4* Bs = Bs0 + buf * BSZ;
+            for (int tl = 0; tl < tg; ++tl) {
+                const int off = tapoff[t0 + tl];
+#pragma unroll
+                for (int sc = 0; sc < 2; ++sc) {
+                    const f32x4 bf = Bs[(tl * 4 + sc * 2 + h) * BN + wn * 32 + li];
+                    f32x4 af[MT];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const int hp = pixbase[m] + off;
+                        af[m] = As[hp * 4 + ((sc * 2 + h) ^ ssie_swz(hp))];
+                    }
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[m] = MFMA_BF16(af[m], bf, acc[m]);
+                }
+            }
+            if (tid == 0 && step == 0 && nsteps > 1 && p.tile_counter)
+                fetched = (int)gridDim.x + atomicAdd(p.tile_counter, 1);
+            chunk = nchunk; g = ng; a_cur = a_nxt;
+        }
+
+        const int co = co0 + wn * 32 + li;
+        if (co < p.Cout) {
+            const float bv = p.bias ? p.bias[co] : 0.f;
+            const long rowstride = (long)p.so * p.Wout * p.out_cstride;
+            const long pixstride = (long)p.so * p.out_cstride;
+            const bool full = a0 + TH <= p.Ho && b0 + SSIE_TW <= p.Wo &&
+                              (a0 + TH - 1) * p.so + p.py < p.Hout && (b0 + SSIE_TW - 1) * p.so + p.px < p.Wout;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int mt = wm * MT + m;
+                const int arow = a0 + 2 * mt, bcol = b0 + 4 * h;
+                const size_t o0 = ((size_t)(n * p.Hout + arow * p.so + p.py) * p.Wout + bcol * p.so + p.px) * p.out_cstride + p.out_coff + co;
+                ssie_epilogue_h(p, acc[m], o0, rowstride, pixstride, bv, full, arow, bcol);
+            }
+        }
+        n = nn; a0 = na0; b0 = nb0; co0 = nco0; tile = ntile;
+    }
+#undef H_PREFETCH
+#undef H_DECODE
+}
+
+#define INST_H(NT, NA2, TH) template __global__ void conv_fprop_bf16_kernel<NT, NA2, TH>(const ConvParams);
+INST_H(2, 3, 16) INST_H(2, 5, 16) INST_H(1, 3, 16) INST_H(1, 5, 16) INST_H(2, 5, 8)
+
+static size_t lds_bytes_h(const ConvParams& p, int nt)
+{
+    return 2 * ((size_t)p.hp_h * p.hp_w * 64 + (size_t)SSIE_TG * 4 * 32 * nt * 16) + (size_t)SSIE_MAX_TAPS * 4 + 16;
+}
+
+template <int NT, int NA2, int TH>
+static int launch_h_t(const ConvParams& p, size_t lds, hipStream_t st)
+{
+    static bool set = false;
+    if (!set) { hipFuncSetAttribute((const void*)conv_fprop_bf16_kernel<NT, NA2, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    const size_t tiles = (size_t)p.N * p.tiles_y * p.tiles_x * p.co_blocks;
+    const size_t wgs = tiles < 256 ? tiles : 256;
+    hipLaunchKernelGGL((conv_fprop_bf16_kernel<NT, NA2, TH>), dim3((unsigned)wgs), dim3(512), lds, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : 61;
+}
+
+// p must come from ssie_make_conv_bf16 (th = 16 for stride 1, 8 for stride 2; 32-channel chunks)
+int ssie_launch_fprop_bf16(const ConvParams& p, hipStream_t st)
+{
+    const int nt = (p.Cout_pad % 64 == 0) ? 2 : 1;
+    const int na2 = (p.hp_h * p.hp_w * 4 + 511) / 512;
+    const size_t lds = lds_bytes_h(p, nt);
+    if (na2 > 5 || lds > 160 * 1024) return 62;
+    if (p.th == 8) return nt == 2 ? launch_h_t<2, 5, 8>(p, lds, st) : 63;
+    if (p.th != 16) return 64;
+    if (nt == 2) return na2 <= 3 ? launch_h_t<2, 3, 16>(p, lds, st) : launch_h_t<2, 5, 16>(p, lds, st);
+    return na2 <= 3 ? launch_h_t<1, 3, 16>(p, lds, st) : launch_h_t<1, 5, 16>(p, lds, st);
+}

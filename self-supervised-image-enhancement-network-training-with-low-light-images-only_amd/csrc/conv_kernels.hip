@@ -554,9 +554,29 @@ __device__ __forceinline__ void ssie_pack_one(const PackDesc& d, long idx4)
     int n = (int)(idx4 % d.Npad); long r = idx4 / d.Npad;
     int q = (int)(r & 3); r >>= 2;
     int t = (int)(r % d.T); int chunk = (int)(r / d.T);
+    const int ts = (int)d.tapsel[t] * d.s_t;
+    if (d.bf16) {          // 8 bf16 (round to nearest even) per 16-byte slot
+        const int kb8 = chunk * 32 + q * 8;
+        unsigned w[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            unsigned pr = 0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int k = kb8 + 2 * s2 + e;
+                const float f = (k < d.K && n < d.N) ? d.w[(long)n * d.s_n + (long)k * d.s_k + ts] : 0.f;
+                unsigned u = __float_as_uint(f);
+                u += 0x7fffu + ((u >> 16) & 1u);
+                pr |= (u >> 16) << (16 * e);
+            }
+            w[s2] = pr;
+        }
+        f32x4 o = {__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3])};
+        ((f32x4*)d.dst)[idx4] = o;
+        return;
+    }
     f32x4 v;
     const int kb = chunk * 16 + (q >> 1) * 8 + (q & 1) * 4;
-    const int ts = (int)d.tapsel[t] * d.s_t;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         int k = kb + s;

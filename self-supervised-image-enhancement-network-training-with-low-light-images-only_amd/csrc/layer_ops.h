@@ -15,10 +15,15 @@ TapList ssie_taps_transposed(int k, int pad, int py, int px);
 SrcDesc ssie_make_src(const float* ptr, int C, int cstride, int coff, int Hs, int Ws, int Hv, int Wv);
 size_t ssie_packed_floats(int K, int N, int T);
 PackDesc ssie_make_pack(const float* w, float* dst, int K, int N, const TapList& t, int s_k, int s_n, int s_t);
+PackDesc ssie_make_pack_bf16(const float* w, float* dst, int K, int N, const TapList& t, int s_k, int s_n, int s_t);
 int ssie_make_conv(ConvParams& p, const SrcDesc* srcs, int nsrc, int N, int Hv, int Wv, const TapList& t, int si,
                    int Ho, int Wo, const float* wpacked, int Cout,
                    float* out, int Hout, int Wout, int out_cstride, int out_coff, int so, int py, int px,
                    const Epilogue& e);
+int ssie_make_conv_bf16(ConvParams& p, const SrcDesc* srcs, int nsrc, int N, int Hv, int Wv, const TapList& t, int si,
+                        int Ho, int Wo, const float* wpacked, int Cout,
+                        float* out, int out_bf16, int Hout, int Wout, int out_cstride, int out_coff, int so, int py, int px,
+                        const Epilogue& e);
 int ssie_make_wgrad(WgradParams& p, const SrcDesc& src, int N, int Hv, int Wv, int ci0_weight,
                     const float* g, int g_cstride, int g_coff, int Cout, int Ho, int Wo, int si,
                     const TapList& t, float* slabs, int target_wgs);

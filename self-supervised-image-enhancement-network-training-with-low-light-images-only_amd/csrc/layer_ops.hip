@@ -112,6 +112,37 @@ int ssie_make_conv(ConvParams& p, const SrcDesc* srcs, int nsrc, int N, int Hv, 
     return 0;
 }
 
+// geometry for conv_fprop_bf16_kernel: bf16 sources (channel counts / strides / offsets multiples of 8, concat pieces
+// multiples of 32), 32-channel chunks, 16 x 16 tiles for stride 1 and 8 x 16 for stride 2
+int ssie_make_conv_bf16(ConvParams& p, const SrcDesc* srcs, int nsrc, int N, int Hv, int Wv, const TapList& t, int si,
+                        int Ho, int Wo, const float* wpacked, int Cout,
+                        float* out, int out_bf16, int Hout, int Wout, int out_cstride, int out_coff, int so, int py, int px,
+                        const Epilogue& e)
+{
+    int rc = ssie_make_conv(p, srcs, nsrc, N, Hv, Wv, t, si, Ho, Wo, wpacked, Cout, out, Hout, Wout, out_cstride, out_coff, so, py, px, e);
+    if (rc) return rc;
+    if (e.mask_y || e.accumulate || (si != 1 && si != 2)) return SSIE_E_ARG;
+    for (int s = 0; s < nsrc; ++s) {
+        if (srcs[s].C % 8 || srcs[s].cstride % 8 || srcs[s].coff % 8) return SSIE_E_SHAPE;
+        if (nsrc > 1 && srcs[s].C % 32) return SSIE_E_SHAPE;
+    }
+    int mny, mxy, mnx, mxx; tap_extent(t, mny, mxy, mnx, mxx);
+    p.nchunks = ssie_ceil_div(p.Cin, 32);
+    p.th = si == 1 ? 16 : 8;
+    p.hp_h = (p.th - 1) * si + (mxy - mny) + 1;
+    p.hp_w = (SSIE_TW - 1) * si + (mxx - mnx) + 1;
+    p.tiles_y = ssie_ceil_div(Ho, p.th);
+    p.out_bf16 = out_bf16;
+    return 0;
+}
+
+PackDesc ssie_make_pack_bf16(const float* w, float* dst, int K, int N, const TapList& t, int s_k, int s_n, int s_t)
+{
+    PackDesc d = ssie_make_pack(w, dst, K, N, t, s_k, s_n, s_t);
+    d.nchunks = ssie_ceil_div(K, 32); d.bf16 = 1;
+    return d;
+}
+
 int ssie_make_wgrad(WgradParams& p, const SrcDesc& src, int N, int Hv, int Wv, int ci0_weight,
                     const float* g, int g_cstride, int g_coff, int Cout, int Ho, int Wo, int si,
                     const TapList& t, float* slabs, int target_wgs)

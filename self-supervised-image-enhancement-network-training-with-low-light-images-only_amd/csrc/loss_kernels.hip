@@ -329,3 +329,26 @@ int ssie_launch_adam(float* p, const float* g, float* m, float* v, long n, float
                        (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), eps);
     return hipGetLastError() == hipSuccess ? 0 : 48;
 }
+
+// ---------------------------------------------------------------------------------------------
+// fp32 -> bf16 conversion for the bf16 inference path
+// ---------------------------------------------------------------------------------------------
+__global__ void to_bf16_kernel(const f32x4* __restrict__ src, uint2* __restrict__ dst, long n4)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = src[i];
+        unsigned u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { unsigned b = __float_as_uint(v[k]); b += 0x7fffu + ((b >> 16) & 1u); u[k] = b >> 16; }
+        dst[i] = make_uint2(u[0] | (u[1] << 16), u[2] | (u[3] << 16));
+    }
+}
+
+int ssie_launch_to_bf16(const float* src, void* dst, long n, hipStream_t st)
+{
+    if (n % 4) return 71;
+    const long n4 = n / 4;
+    long blocks = (n4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const f32x4*)src, (uint2*)dst, n4);
+    return hipGetLastError() == hipSuccess ? 0 : 72;
+}

@@ -55,6 +55,8 @@ struct Plan {
     std::vector<PackDesc> packs;
     size_t pack_cursor = 0, pack_floats_total = 0, pack_off = 0;
     std::vector<Fn> fwd, pass2, lossbwd;
+    std::vector<Fn> fwd16;       // enhance-only forward with bf16 storage / bf16 MFMA (ssie_plan_enhance_fwd_bf16)
+    size_t npacks_train = 0;     // packs[0 .. npacks_train) belong to the fp32 lists, the rest to fwd16
     bool bound = false;
     // the slab reductions (HBM-bound) run on a side stream underneath the next MFMA-bound launches; wgrad launches
     // alternate between two slab areas so that a reduction only has to finish before the wgrad AFTER the next one
@@ -150,6 +152,8 @@ void build_buffers(Plan& pl)
     alloc(pl, "Gf", N, H, W, 64); alloc(pl, "gd3", N, H, W, 64); alloc(pl, "Ge3", N, H, W, 64); alloc(pl, "tmpH", N, H, W, 64);
     alloc(pl, "gd2", N, H2, W2, 64); alloc(pl, "Ge2", N, H2, W2, 64); alloc(pl, "gd1", N, H4, W4, 64); alloc(pl, "Ge1", N, H4, W4, 64);
     alloc(pl, "gt3", N, H8, W8, 64); alloc(pl, "gf1", N, H8, W8, 64); alloc(pl, "gao", N, H8, W8, 64); alloc(pl, "gqkv", N, H8, W8, 192);
+    // bf16 inference path: bf16 copies of the tensors that also exist in fp32 (allocated in float units: C/2)
+    alloc(pl, "xh", N, H, W, ssie_round_up(B, 8) / 2); alloc(pl, "RLh", N, H, W, ssie_round_up(B + 1, 8) / 2); alloc(pl, "aoh", N, H8, W8, 32);
     // scratch
     pl.slab_cap = (size_t)kWgs * 9 * 64 * 64 + (size_t)81 * ssie_round_up(B + 1, 64) * 128 + (size_t)kWgs * ssie_round_up(B + 1, 64);
     pl.slab_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + pl.slab_cap, 64);
@@ -161,7 +165,7 @@ void build_buffers(Plan& pl)
     pl.scal_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 16, 64);
     pl.mask_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + ((size_t)H * W + 3) / 4, 64);
     pl.counter_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 1024, 64);      // tile-queue counters, one per conv launch
-    pl.packdesc_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 256 * sizeof(PackDesc) / 4, 64);
+    pl.packdesc_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 384 * sizeof(PackDesc) / 4, 64);
     pl.pack_off = pl.ws_floats;     // packed weights grow from here at bind time (size known after a dry build)
 }
 
@@ -169,6 +173,7 @@ void build_buffers(Plan& pl)
 struct Builder {
     Plan& pl;
     bool dry;                 // dry run: only count packed-weight floats
+    bool h16 = false;         // building the bf16 inference list: bf16 sources / packs / kernels
     explicit Builder(Plan& p, bool d) : pl(p), dry(d) { pl.pack_cursor = 0; pl.packs.clear(); pl.counter_cursor = 0; }
 
     float* take_pack(size_t floats)
@@ -179,6 +184,14 @@ struct Builder {
     }
     SrcDesc src(const char* name, int C, int Hv, int Wv, int coff = 0)
     {
+        if (h16) {
+            // bf16 tensors live in the fp32 tensors' allocations (first half); the three that must also exist in fp32
+            // (input cube, R/I output, attention output) have bf16 twins.  Strides are in ELEMENTS either way.
+            const char* hn = !strcmp(name, "x") ? "xh" : !strcmp(name, "RL_1") ? "RLh" : !strcmp(name, "ao") ? "aoh" : name;
+            const BufInfo& b = pl.bi(hn);
+            const int cs = hn != name ? b.cs * 2 : b.cs;
+            return ssie_make_src(dry ? nullptr : pl.buf(hn), ssie_round_up(C, 8), ssie_round_up(cs, 8), coff, b.H, b.W, Hv, Wv);
+        }
         const BufInfo& b = pl.bi(name);
         return ssie_make_src(dry ? nullptr : pl.buf(name), C, b.cs, coff, b.H, b.W, Hv, Wv);
     }
@@ -193,8 +206,15 @@ struct Builder {
         const double fl = 2.0 * p.N * p.Ho * p.Wo * (double)p.Cout * k_real * p.ntaps;
         char tag[96];
         snprintf(tag, sizeof(tag), "conv k%d->n%d taps%d si%d so%d %dx%d", k_real, p.Cout, p.ntaps, p.si, p.so, p.Ho, p.Wo);
+        if (h16) {
+            std::string t16 = std::string("bf16 ") + tag;
+            ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_fprop_bf16(p, st); }, p.Cout_pad % 64 == 0 ? K_FPROP2 : K_FPROP1, fl, t16));
+            return;
+        }
         ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_fprop(p, st); }, p.Cout_pad % 64 == 0 ? K_FPROP2 : K_FPROP1, fl, tag));
     }
+    // bf16 list: which outputs stay fp32 (API outputs and the attention operands)
+    static bool out_is_f32(const char* out) { return !strcmp(out, "RL_1") || !strcmp(out, "qkv") || !strcmp(out, "D"); }
 
     // forward conv (stride 1/2) over concatenated / up-sampled sources
     int conv(std::vector<Fn>& ops, const LayerP& L, std::vector<SrcDesc> srcs, int Hv, int Wv, int stride,
@@ -204,13 +224,24 @@ struct Builder {
         TapList t = ssie_taps_conv(L.k);
         float* wp = take_pack(ssie_packed_floats(L.cin, L.cout, T));
         if (dry) return 0;
-        pl.packs.push_back(ssie_make_pack(pl.P + L.w, wp, L.cin, L.cout, t, T, L.cin * T, 1));
         const BufInfo& ob = pl.bi(out);
         Epilogue e; memset(&e, 0, sizeof(e)); e.bias = pl.P + L.b; e.act = act;
         e.addsrc = addsrc ? pl.buf(addsrc) : nullptr; e.out2 = out2 ? pl.buf(out2) : nullptr;
         const int Ho = (Hv + 2 * pad - L.k) / stride + 1, Wo = (Wv + 2 * pad - L.k) / stride + 1;
         if (Ho != ob.H || Wo != ob.W) return SSIE_E_SHAPE;
         ConvParams p;
+        if (h16) {
+            pl.packs.push_back(ssie_make_pack_bf16(pl.P + L.w, wp, L.cin, L.cout, t, T, L.cin * T, 1));
+            // the pre-skip copies (u1..u3) only serve the backward pass; the R/I output gets its bf16 twin instead
+            e.out2 = !strcmp(out, "RL_1") ? pl.buf("RLh") : nullptr;
+            const int f32o = out_is_f32(out);
+            int rc = ssie_make_conv_bf16(p, srcs.data(), (int)srcs.size(), pl.N, Hv, Wv, t, stride, Ho, Wo, wp, L.cout,
+                                         pl.buf(out), !f32o, ob.H, ob.W, f32o ? ob.cs : ssie_round_up(ob.cs, 8), out_coff, 1, 0, 0, e);
+            if (rc) return rc;
+            push(ops, p, L.cin);
+            return 0;
+        }
+        pl.packs.push_back(ssie_make_pack(pl.P + L.w, wp, L.cin, L.cout, t, T, L.cin * T, 1));
         int rc = ssie_make_conv(p, srcs.data(), (int)srcs.size(), pl.N, Hv, Wv, t, stride, Ho, Wo, wp, L.cout,
                                 pl.buf(out), ob.H, ob.W, ob.cs, out_coff, 1, 0, 0, e);
         if (rc) return rc;
@@ -227,9 +258,16 @@ struct Builder {
             TapList t = ssie_taps_transposed(3, 1, py, px);
             float* wp = take_pack(ssie_packed_floats(Kc, Nc, t.n));
             if (dry) continue;
-            pl.packs.push_back(ssie_make_pack(wbase, wp, Kc, Nc, t, s_k, s_n, 1));
             ConvParams p;
             const int Ho = ssie_ceil_div(ob.H - py, 2), Wo = ssie_ceil_div(ob.W - px, 2);
+            if (h16) {
+                pl.packs.push_back(ssie_make_pack_bf16(wbase, wp, Kc, Nc, t, s_k, s_n, 1));
+                int rc = ssie_make_conv_bf16(p, &in, 1, pl.N, Hin, Win, t, 1, Ho, Wo, wp, Nc, pl.buf(out), 1, ob.H, ob.W, ob.cs, 0, 2, py, px, e);
+                if (rc) return rc;
+                push(ops, p, Kc);
+                continue;
+            }
+            pl.packs.push_back(ssie_make_pack(wbase, wp, Kc, Nc, t, s_k, s_n, 1));
             int rc = ssie_make_conv(p, &in, 1, pl.N, Hin, Win, t, 1, Ho, Wo, wp, Nc, pl.buf(out), ob.H, ob.W, ob.cs, 0, 2, py, px, e);
             if (rc) return rc;
             push(ops, p, Kc);
@@ -370,6 +408,10 @@ int build_illum_fwd(Builder& b, std::vector<Fn>& ops)
         const float* qkv = pl.buf("qkv"); float* ao = pl.buf("ao"); float* lse = pl.buf("lse");
         const int N = pl.N, T = H8 * W8;
         ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_attn_fwd(qkv, 192, ao, 64, lse, N, T, st); }, K_ATTN, 4.0 * N * 4 * (double)T * T * 16));
+        if (b.h16) {
+            float* aoh = pl.buf("aoh"); const long ne = (long)N * T * 64;
+            ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_to_bf16(ao, aoh, ne, st); }));
+        }
     }
     CK(b.conv(ops, layer(pl, i + "attn.ff_linear1"), {b.src("ao", 64, H8, W8)}, H8, W8, 1, "f1", ACT_RELU));
     CK(b.conv(ops, layer(pl, i + "attn.ff_linear2"), {b.src("f1", 64, H8, W8)}, H8, W8, 1, "t3", ACT_NONE, "a3"));
@@ -555,6 +597,19 @@ int build_all(Plan& pl, bool dry)
     CK(build_illum_bwd(b, ops));
     b.mask_axpy(ops, "gRL", "RL_1", MASK_SIGMOID, "G8", pl.B + 1, 0);
     CK(build_decomposition_bwd(b, ops, "x", 1, false));
+    // bf16 inference list (its packs follow the fp32 ones)
+    pl.npacks_train = pl.packs.size();
+    pl.fwd16.clear();
+    if (pl.CX % 8 == 0 && pl.CRL % 8 == 0) {      // bf16 pixels are read in 16-byte (8-channel) slots; e.g. B = 31, 63, 127
+        b.h16 = true;
+        if (!b.dry) {
+            const float* xf = pl.buf("x"); float* xh = pl.buf("xh"); const long ne = (long)pl.N * pl.H * pl.W * pl.CX;
+            pl.fwd16.push_back(Fn([=](hipStream_t st) { return ssie_launch_to_bf16(xf, xh, ne, st); }));
+        }
+        CK(build_decomposition_fwd(b, pl.fwd16, "x", 1));
+        CK(build_illum_fwd(b, pl.fwd16));
+        b.h16 = false;
+    }
     pl.pack_floats_total = pl.pack_cursor;
     return 0;
 }
@@ -674,7 +729,7 @@ extern "C" int ssie_plan_bind(void* h, void* workspace, size_t ws_bytes, float* 
     if (hipMemsetAsync(workspace, 0, pl->ws_floats * 4, st) != hipSuccess) return SSIE_E_LAUNCH;
     int rc = build_all(*pl, false);
     if (rc) return rc;
-    if (pl->packs.size() > 256) return SSIE_E_WORKSPACE;
+    if (pl->packs.size() > 384) return SSIE_E_WORKSPACE;
     if (hipMemcpyAsync(pl->ws + pl->packdesc_off, pl->packs.data(), pl->packs.size() * sizeof(PackDesc), hipMemcpyHostToDevice, st) != hipSuccess) return SSIE_E_LAUNCH;
     if (ssie_fft_supported(pl->H, pl->W)) {
         std::vector<uint8_t> m((size_t)pl->H * pl->W);
@@ -690,7 +745,14 @@ static int pack_all(Plan* pl, hipStream_t st)
 {
     // tile-queue counters of every conv launch of this step (one memset node)
     if (hipMemsetAsync(pl->ws + pl->counter_off, 0, 1024 * 4, st) != hipSuccess) return SSIE_E_LAUNCH;
-    return ssie_launch_pack_batched((const PackDesc*)(pl->ws + pl->packdesc_off), (int)pl->packs.size(), st) ? SSIE_E_LAUNCH : 0;
+    return ssie_launch_pack_batched((const PackDesc*)(pl->ws + pl->packdesc_off), (int)pl->npacks_train, st) ? SSIE_E_LAUNCH : 0;
+}
+
+static int pack_all_bf16(Plan* pl, hipStream_t st)
+{
+    if (hipMemsetAsync(pl->ws + pl->counter_off, 0, 1024 * 4, st) != hipSuccess) return SSIE_E_LAUNCH;
+    const int n16 = (int)(pl->packs.size() - pl->npacks_train);
+    return ssie_launch_pack_batched((const PackDesc*)(pl->ws + pl->packdesc_off) + pl->npacks_train, n16, st) ? SSIE_E_LAUNCH : 0;
 }
 
 static int ingest(Plan* pl, const float* x, const long* strides4, hipStream_t st)
@@ -707,6 +769,19 @@ extern "C" int ssie_plan_enhance_fwd(void* h, const float* x, const long* stride
     CK(pack_all(pl, st));
     CK(ingest(pl, x, strides4, st));
     return run_ops(pl->fwd, st);
+}
+
+// enhance-only forward with bf16 activations / weights and bf16 MFMA (fp32 accumulate, fp32 bias / activation / attention);
+// the four outputs (RL_1 = R|I, D, S) are fp32 like ssie_plan_enhance_fwd's
+extern "C" int ssie_plan_enhance_fwd_bf16(void* h, const float* x, const long* strides4, void* stream)
+{
+    Plan* pl = (Plan*)h;
+    if (!pl || !pl->bound || !x || !strides4) return SSIE_E_ARG;
+    if (pl->fwd16.empty()) return SSIE_E_SHAPE;      // band count not a multiple of 8 after padding: use the fp32 path
+    hipStream_t st = (hipStream_t)stream;
+    CK(pack_all_bf16(pl, st));
+    CK(ingest(pl, x, strides4, st));
+    return run_ops(pl->fwd16, st);
 }
 
 extern "C" int ssie_plan_loss_fwd_bwd(void* h, const float* x, const long* strides4, int with_backward, void* stream)
@@ -797,6 +872,42 @@ extern "C" int ssie_plan_profile_ops(void* h, const float* x, const long* stride
     for (auto& e : ev) hipEventDestroy(e);
     if (tags && tags_cap > 0) { strncpy(tags, all.c_str(), tags_cap - 1); tags[tags_cap - 1] = 0; }
     return (int)seq.size();
+}
+
+// per-launch timing of ONE op list (dev tool): which = 0 enhance forward (fp32), 1 = bf16 enhance forward
+extern "C" int ssie_plan_profile_list(void* h, const float* x, const long* strides4, void* stream, int which,
+                                      double* ms, double* flops, int* kinds, int cap, char* tags, int tags_cap)
+{
+    Plan* pl = (Plan*)h;
+    if (!pl || !pl->bound || !x || !strides4) return -SSIE_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<Fn>& seq = which == 1 ? pl->fwd16 : pl->fwd;
+    if ((int)seq.size() > cap) return -SSIE_E_WORKSPACE;
+    std::vector<hipEvent_t> ev(seq.size() + 1);
+    for (auto& e : ev) hipEventCreate(&e);
+    if (which == 1) pack_all_bf16(pl, st); else pack_all(pl, st);
+    ingest(pl, x, strides4, st);
+    hipEventRecord(ev[0], st);
+    for (size_t i = 0; i < seq.size(); ++i) { seq[i](st); hipEventRecord(ev[i + 1], st); }
+    hipStreamSynchronize(st);
+    std::string all;
+    for (size_t i = 0; i < seq.size(); ++i) {
+        float t = 0.f; hipEventElapsedTime(&t, ev[i], ev[i + 1]);
+        ms[i] = t; flops[i] = seq[i].flops; kinds[i] = seq[i].kind;
+        all += seq[i].tag; all += "\n";
+    }
+    for (auto& e : ev) hipEventDestroy(e);
+    if (tags && tags_cap > 0) { strncpy(tags, all.c_str(), tags_cap - 1); tags[tags_cap - 1] = 0; }
+    return (int)seq.size();
+}
+
+// number of launches in the three op lists (enhance forward, second decomposition pass, loss + backward)
+extern "C" int ssie_plan_num_ops(void* h, int* counts3)
+{
+    Plan* pl = (Plan*)h;
+    if (!pl || !counts3) return SSIE_E_ARG;
+    counts3[0] = (int)pl->fwd.size(); counts3[1] = (int)pl->pass2.size(); counts3[2] = (int)pl->lossbwd.size();
+    return 0;
 }
 
 extern "C" int ssie_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n,

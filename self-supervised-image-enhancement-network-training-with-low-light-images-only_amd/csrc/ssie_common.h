@@ -62,6 +62,7 @@ struct ConvParams {
     int tiles_y, tiles_x, co_blocks;
     int th;                 // output tile rows: 8, or 16 for the stride-1 3x3 / 1x1 layers
     int* tile_counter;      // optional dynamic tile queue (device int, zero before the launch); null = static stride
+    int out_bf16;           // bf16 inference kernel only: element type of `out` (addsrc / out2 are always bf16 there)
 };
 
 struct WgradParams {
@@ -88,12 +89,14 @@ struct PackDesc {
     int K, N, Npad, T, nchunks;
     int s_k, s_n, s_t;
     int8_t tapsel[SSIE_MAX_TAPS];
+    int bf16;               // 1: pack for the bf16 kernel - dst[chunk32][t][slot 0..3][n][8 bf16], k = chunk*32 + 8*slot + s
 };
 
 // host launchers (conv_kernels.hip); return 0 on success
 int ssie_launch_fprop(const ConvParams& p, hipStream_t st);
 bool ssie_fprop_v2_ok(const ConvParams& p);            // conv_fprop_v2.hip
 int ssie_launch_fprop_v2(const ConvParams& p, hipStream_t st);
+int ssie_launch_fprop_bf16(const ConvParams& p, hipStream_t st);   // conv_fprop_bf16.hip; p from ssie_make_conv_bf16
 extern int ssie_fprop_use_v2;                          // tuning / A-B switch (1 = use the 512-thread DMA kernel when eligible)
 int ssie_launch_wgrad(const WgradParams& p, hipStream_t st);
 int ssie_launch_wgrad_reduce(const float* slabs, int nslices, int ntaps, int ci_pad, int co_pad, int Cin, int Cout,

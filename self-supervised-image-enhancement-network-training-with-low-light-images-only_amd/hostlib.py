@@ -193,6 +193,7 @@ def _proto():
     L.ssie_plan_set_coefs.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.ssie_plan_bind.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ssie_plan_enhance_fwd.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_long), C.c_void_p]
+    L.ssie_plan_enhance_fwd_bf16.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_long), C.c_void_p]
     L.ssie_plan_loss_fwd_bwd.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_long), C.c_int, C.c_void_p]
     L.ssie_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float,
                                  C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]
@@ -275,7 +276,12 @@ class Plan:
             raise SsieError(f"expected float32 cuda tensor of shape {(n, b, h, w)}, got {tuple(x.shape)} {x.dtype} {x.device}")
         return (C.c_long * 4)(*x.stride())
 
-    def enhance_fwd(self, x):
+    def enhance_fwd(self, x, bf16=False):
+        """model.py:229-234 into the plan buffers; bf16=True: bf16 storage + bf16 MFMA (fp32 accumulate), fp32 outputs"""
+        if bf16:
+            check(self.L.ssie_plan_enhance_fwd_bf16(self.h, x.data_ptr(), self._strides(x), torch.cuda.current_stream().cuda_stream),
+                  "ssie_plan_enhance_fwd_bf16")
+            return
         check(self.L.ssie_plan_enhance_fwd(self.h, x.data_ptr(), self._strides(x), torch.cuda.current_stream().cuda_stream),
               "ssie_plan_enhance_fwd")
 

@@ -146,6 +146,8 @@ class LowLightEnhance(nn.Module):
         self.save_reflectance, self.save_illumination, self.save_i_delta = save_reflectance, save_illumination, save_i_delta
         self.eval_metrics = {}
         self.freeze_decom_epochs = 0
+        # opt-in (not a reference kwarg): forward() under torch.no_grad() uses bf16 storage + bf16 MFMA; outputs stay fp32
+        self.bf16_inference = False
         self.all_epoch_losses = {k: [] for k in LOSS_KEYS}
 
         self._table, total = H.param_table(input_channels)
@@ -239,7 +241,8 @@ class LowLightEnhance(nn.Module):
         """model.py:229-234.  Returns views into the plan workspace (valid until the next call on this shape)."""
         x = self._f32(input_low)
         plan = self._plan_for(x)
-        plan.enhance_fwd(x)
+        # mixed-precision inference (BASELINE.json configs[4]): only outside autograd, training always runs fp32
+        plan.enhance_fwd(x, bf16=bool(self.bf16_inference) and not torch.is_grad_enabled())
         b = self.input_channels
         return plan.nchw("RL_1", 0, b), plan.nchw("RL_1", b, b + 1), plan.nchw("D", 0, 1), plan.nchw("S", 0, b)
 

@@ -1,0 +1,66 @@
+"""bf16 mixed-precision enhance-only path (BASELINE.json configs[4]) against the fp64 CPU oracle.
+
+The reference has no reduced-precision mode (model.py:229-234 runs fp32), so there is no reference tolerance to inherit:
+the bars below are this build's own, set from what bf16 storage (8-bit mantissa, relative step 2^-8) can deliver through
+the ~20-layer path with fp32 accumulation - they are NOT the fp32 path's 1e-5 bar, which test_plan_gpu.py keeps."""
+import math
+
+import pytest
+import torch
+
+from oracle import ssie_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    import ssie
+    ssie.load()
+    from ssie_amd import hostlib
+    assert hostlib.lib().ssie_device_ok() == 1
+    return hostlib
+
+
+def _plan(H, n, bands, h, w):
+    table, total = H.param_table(bands)
+    P = O.closed_form_params(bands)
+    flat = torch.zeros(total, device="cuda")
+    for name, off, shape in table:
+        flat[off:off + P[name].numel()] = P[name].reshape(-1).cuda()
+    return H.Plan(n, bands, h, w, O.JYU_COEFS, flat, torch.zeros_like(flat)), P
+
+
+@pytest.mark.parametrize("n,bands,h,w", [(2, 31, 64, 64), (1, 31, 50, 38), (1, 31, 136, 200), (1, 7, 32, 32)])
+def test_bf16_enhance_vs_oracle(H, n, bands, h, w):
+    plan, P = _plan(H, n, bands, h, w)
+    x = O.synthetic_patches(n, bands, h, w)
+    plan.enhance_fwd(x.cuda(), bf16=True)
+    torch.cuda.synchronize()
+    R, I, D, S = O.enhance_forward({k: v.double() for k, v in P.items()}, x.double())
+    B = bands
+    got = dict(R=plan.nchw("RL_1", 0, B), I=plan.nchw("RL_1", B, B + 1), D=plan.nchw("D", 0, 1), S=plan.nchw("S", 0, B))
+    ref = dict(R=R, I=I, D=D, S=S)
+    rep = {}
+    for k in got:
+        g = got[k].cpu().double()
+        assert torch.isfinite(g).all(), k
+        err = (g - ref[k]).abs().max().item()
+        mse = ((g - ref[k]) ** 2).mean().item()
+        rep[k] = (err, 10 * math.log10(1.0 / max(mse, 1e-30)))
+    print({k: (f"{e:.2e}", f"{p:.1f} dB") for k, (e, p) in rep.items()})
+    for k, (err, psnr) in rep.items():
+        assert err <= 5e-3, (k, err)            # outputs live in [0, 1]; measured 4e-5 (R, I) .. 9e-4 (I_delta)
+        assert psnr >= 60.0, (k, psnr)          # data_range 1 (metrics.py:122 convention); measured 72 .. 100 dB
+    # the fp32 path on the same plan must be untouched by the bf16 run (shared workspace, separate op lists)
+    plan.enhance_fwd(x.cuda())
+    torch.cuda.synchronize()
+    assert (plan.nchw("S", 0, B).cpu().double() - S).abs().max() <= 1e-5
+
+
+def test_bf16_unsupported_band_count_fails_loudly(H):
+    """bf16 pixels are fetched in 8-channel slots: a padded band count that is not a multiple of 8 must raise, not fall back"""
+    plan, P = _plan(H, 1, 9, 16, 16)
+    x = O.synthetic_patches(1, 9, 16, 16)
+    with pytest.raises(H.SsieError):
+        plan.enhance_fwd(x.cuda(), bf16=True)
