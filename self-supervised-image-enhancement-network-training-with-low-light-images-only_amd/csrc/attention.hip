@@ -4,32 +4,61 @@
 // layers (:104-106, :115-117) run on the MFMA 1x1-conv path.
 //
 // Tokens are the NHWC pixels of the bottleneck feature map, so the (N*T, 192) qkv buffer is read
-// directly; one thread owns one query row (forward, dQ) or one key row (dK, dV) and streams the other
-// side through LDS in tiles of 256 rows with an online softmax, so any token count works (256 tokens
+// directly; the forward is an fp32-MFMA flash attention (below); in the backward one thread owns one query row (dQ) or
+// one key row (dK, dV) and streams the other side through LDS in tiles of 256 rows, so any token count works (256 tokens
 // for a 128x128 patch, 16 384 for a 1024x1024 image) without materialising the T x T logits.
 #include "attention.h"
 
 #define AT_D 16
 #define AT_TILE 256
 
+// Forward: fp32-MFMA flash attention.  One wave owns 32 queries of one head; per block of 32 keys it computes
+//   S^T = K Q^T      (32 keys x 32 queries, 8 x v_mfma_f32_32x32x2_f32 over the 16 head dims), then
+//   O^T += V^T P^T   (16 dims (padded to 32 rows) x 32 queries, 16 MFMAs over the 32 keys)
+// Working on the TRANSPOSED logits puts the query on the lane axis of the accumulator layout, so (a) the online-softmax
+// state (running max / sum / rescale) is one scalar per lane, and (b) the probabilities P^T already sit in registers in
+// exactly the B-operand layout of the second product: accumulator register s of lane (q, h) is key row
+// (s&3) + 8*(s>>2) + 4h, which we simply DEFINE as the h-th key of contraction step s (the order of a sum is free), and
+// V^T is fetched from LDS to match.  No shuffle, no LDS round trip for P.  The two lane halves of a query share the
+// running max (one cross-half exchange per block) and keep separate partial sums, joined once at the end.
+#define AQ_WG 128        // queries per workgroup (4 waves x 32)
+#define AK_ST 64         // keys staged in LDS per iteration
+#define AK_LD 20         // padded LDS row (floats): 16-byte aligned rows, conflict-free 128-bit reads
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, int qs, float* __restrict__ o, int os,
                                                        float* __restrict__ lse, int T, float scale)
 {
-    __shared__ float Ks[AT_TILE][AT_D];
-    __shared__ float Vs[AT_TILE][AT_D];
-    const int tid = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float Ks[AK_ST][AK_LD];
+    __shared__ __attribute__((aligned(16))) float Vs[AK_ST][AK_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, li = lane & 31;
     const int head = blockIdx.y, n = blockIdx.z;
-    const int qi = blockIdx.x * 256 + tid;
+    const int qi = blockIdx.x * AQ_WG + wave * 32 + li;
     const float* base = qkv + (size_t)n * T * qs;
-    float q[AT_D], acc[AT_D];
+
+    // B operand of S^T: lane (q, h) supplies Q[q][8h + s] * scale at contraction step s
+    float qb[8];
+    {
+        f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0;
+        if (qi < T) {
+            q0 = *(const f32x4*)(base + (size_t)qi * qs + head * AT_D + 8 * h);
+            q1 = *(const f32x4*)(base + (size_t)qi * qs + head * AT_D + 8 * h + 4);
+        }
 #pragma unroll
-    for (int d = 0; d < AT_D; ++d) { q[d] = qi < T ? base[(size_t)qi * qs + head * AT_D + d] * scale : 0.f; acc[d] = 0.f; }
-    float m = -INFINITY, l = 0.f;
-    for (int k0 = 0; k0 < T; k0 += AT_TILE) {
+        for (int s = 0; s < 4; ++s) { qb[s] = q0[s] * scale; qb[4 + s] = q1[s] * scale; }
+    }
+    f32x16 oacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+    float m = -INFINITY, lsum = 0.f;
+
+    for (int k0 = 0; k0 < T; k0 += AK_ST) {
         __syncthreads();
-        for (int id = tid; id < AT_TILE * 4; id += 256) {
-            const int r = id >> 2, c4 = (id & 3) * 4;
-            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+        {
+            const int r = tid >> 2, c4 = (tid & 3) * 4;
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
             if (k0 + r < T) {
                 kv = *(const f32x4*)(base + (size_t)(k0 + r) * qs + 64 + head * AT_D + c4);
                 vv = *(const f32x4*)(base + (size_t)(k0 + r) * qs + 128 + head * AT_D + c4);
@@ -37,29 +66,53 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
             *(f32x4*)&Ks[r][c4] = kv; *(f32x4*)&Vs[r][c4] = vv;
         }
         __syncthreads();
-        const int kn = min(AT_TILE, T - k0);
-        for (int j = 0; j < kn; ++j) {
-            float s = 0.f;
 #pragma unroll
-            for (int d = 0; d < AT_D; ++d) s += q[d] * Ks[j][d];
-            if (s > m) {
-                const float f = expf(m - s);
-                l *= f;
+        for (int sub = 0; sub < AK_ST / 32; ++sub) {
+            const int kb = k0 + sub * 32;
+            if (kb >= T) break;
+            // S^T = K Q^T: A operand lane (key, h) supplies K[key][8h + s]
+            const f32x4 ka0 = *(const f32x4*)&Ks[sub * 32 + li][8 * h], ka1 = *(const f32x4*)&Ks[sub * 32 + li][8 * h + 4];
+            f32x16 st;
 #pragma unroll
-                for (int d = 0; d < AT_D; ++d) acc[d] *= f;
-                m = s;
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) st = MFMA32(ka0[s], qb[s], st);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) st = MFMA32(ka1[s], qb[4 + s], st);
+            if (kb + 32 > T) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kb + (r & 3) + 8 * (r >> 2) + 4 * h >= T) st[r] = -INFINITY;
             }
-            const float pj = expf(s - m);
-            l += pj;
+            float mb = st[0];
 #pragma unroll
-            for (int d = 0; d < AT_D; ++d) acc[d] += pj * Vs[j][d];
+            for (int r = 1; r < 16; ++r) mb = fmaxf(mb, st[r]);
+            mb = fmaxf(mb, __shfl_xor(mb, 32));
+            const float m_new = fmaxf(m, mb);                 // finite: key kb < T is never masked
+            const float alpha = expf(m - m_new);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[r] = expf(st[r] - m_new); ps += st[r]; }
+            lsum = lsum * alpha + ps;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) oacc[r] *= alpha;     // rows d < 16 of O^T live in registers 0..7
+            m = m_new;
+            // O^T += V^T P^T: step s contracts key rows (s&3) + 8*(s>>2) + 4h
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float a = Vs[sub * 32 + (s & 3) + 8 * (s >> 2) + 4 * h][li & 15];
+                oacc = MFMA32(a, st[s], oacc);
+            }
         }
     }
+    const float ltot = lsum + __shfl_xor(lsum, 32);
     if (qi < T) {
-        const float inv = 1.f / l;
-#pragma unroll
-        for (int d = 0; d < AT_D; ++d) o[((size_t)n * T + qi) * os + head * AT_D + d] = acc[d] * inv;
-        lse[((size_t)n * 4 + head) * T + qi] = m + logf(l);
+        const float inv = 1.f / ltot;
+        float* op = o + ((size_t)n * T + qi) * os + head * AT_D + 4 * h;
+        const f32x4 v0 = {oacc[0] * inv, oacc[1] * inv, oacc[2] * inv, oacc[3] * inv};
+        const f32x4 v1 = {oacc[4] * inv, oacc[5] * inv, oacc[6] * inv, oacc[7] * inv};
+        *(f32x4*)op = v0; *(f32x4*)(op + 8) = v1;
+        if (h == 0) lse[((size_t)n * 4 + head) * T + qi] = m + logf(ltot);
     }
 }
 
@@ -176,7 +229,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
 
 int ssie_launch_attn_fwd(const float* qkv, int qs, float* o, int os, float* lse, int N, int T, hipStream_t st)
 {
-    dim3 grid((T + 255) / 256, 4, N);
+    dim3 grid((T + AQ_WG - 1) / AQ_WG, 4, N);
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, st, qkv, qs, o, os, lse, T, 0.25f);
     return hipGetLastError() == hipSuccess ? 0 : 61;
 }

@@ -25,7 +25,7 @@ CASES = {
     "b31_128": (1, 31, 128, 128, O.JYU_COEFS),       # BASELINE.json configs[1] geometry (one patch of the bench batch)
     "b256_64": (1, 256, 64, 64, O.JYU_COEFS),        # BASELINE.json configs[2]: 256-band cubes
 }
-GRAD_FLOOR = {"b256_64": 5e-3}
+GRAD_FLOOR = {"b256_64": 5e-3}     # 256 bands: cotangent noise 5-7e-2, deep-layer gradients see ~3e-3 of it
 
 
 @pytest.fixture(scope="module")
@@ -70,10 +70,12 @@ def test_stagewise_parity(pkg, case):
     _, grads32, _ = O.loss_and_grads(P, x, coefs, tr32)
     report, bad = [], []
 
-    # 256 bands: the (R,I)/D cotangents carry 5-7e-2 of sg() flip noise in BOTH fp32 evaluations (see the report), and the
-    # deep illumination-net gradients average an independent realisation of it down to ~3e-3; one fp32 oracle run is too
-    # noisy an estimate of that per tensor, so the floor is raised for this case only
-    floor = GRAD_FLOOR.get(case, 1e-3)
+    # Every parameter gradient is a linear functional of the loss cotangents, and those carry the sg() flip noise directly
+    # (d/dD below: 2-7e-2 in BOTH fp32 evaluations).  One fp32 oracle run gives a noisy per-tensor estimate of how much of
+    # it survives the averaging into a deep-layer gradient, so the floor is tied to the cotangent noise itself: a tenth
+    # of the fp32 oracle's own d/dD deviation (never below 1e-3).
+    noise_D = rel_l2(tr32["D"].grad, tr["D"].grad)
+    floor = max(GRAD_FLOOR.get(case, 1e-3), 0.1 * noise_D)
 
     def gtol(ref32, ref64):
         return max(floor, 2.0 * rel_l2(ref32, ref64))
@@ -126,7 +128,7 @@ def test_stagewise_parity(pkg, case):
         if ".q_linear." in name or ".k_linear." in name:
             # dS = P (dP - delta) cancels almost completely for these fixtures (|dq|,|dk| ~ 1e-4 |dv|), so the upstream
             # fp32 sign-flip noise in dO (~7e-4) is amplified; the kernel itself is pinned to 2e-5 in test_attention_gpu.py
-            tol = max(tol, 5e-3)
+            tol = max(tol, 5e-3, 0.3 * noise_D)
         chk("grad " + name, g, grads[name], tol, "rel")
 
     print("\n".join(report))
