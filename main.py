@@ -31,7 +31,7 @@ DEFAULTS = {
     "phase": "train_and_test", "epoch": 400, "eval_every_epoch": 200, "plot_every_epoch": 200,
     "c_loss_reconstruction": 10., "c_loss_r_fidelity": 1., "c_loss_i_smooth_low": 1., "c_loss_i_smooth_delta": 20.,
     "c_loss_fourier": 0.2, "c_loss_spectral_cons": 1., "alpha_i_smooth_low": 1., "alpha_i_smooth_delta": 10.,
-    "save_reflectance": False, "save_illumination": False, "save_i_delta": False, "model_name": "no_name_model",
+    "save_reflectance": False, "save_illumination": False, "save_i_delta": False, "bf16_inference": 0, "model_name": "no_name_model",
     "pretrained_model": "", "freeze_decom_epochs": 0,
 }
 
@@ -84,6 +84,7 @@ def build_model(args, device):
         global_min=args.global_min, global_max=args.global_max, save_reflectance=args.save_reflectance,
         save_illumination=args.save_illumination, save_i_delta=args.save_i_delta)
     net = net.to(device)
+    net.bf16_inference = bool(int(args.bf16_inference))          # extra key (not in the reference): bf16 test/eval forward, fp32 training
     if args.pretrained_model:                                            # main.py:196-212
         ck = torch.load(args.pretrained_model, map_location=device, weights_only=True)
         net.load_state_dict(ck["model_state_dict"] if "model_state_dict" in ck else ck)
