@@ -5,6 +5,8 @@
 #include <string.h>
 
 int ssie_fprop_tile16 = 0;   // tuning knob (tools/): 0 forces 8-row tiles everywhere
+int ssie_fprop_wide = 1;     // 1: 16 x 32 tiles (conv_fprop_v2w_kernel) for the big 64-channel stride-1 3x3 layers
+extern "C" void ssie_debug_set_fprop_wide(int v) { ssie_fprop_wide = v; }
 extern "C" void ssie_debug_set_fprop_tile16(int v) { ssie_fprop_tile16 = v; }
 
 // ---------------------------------------------------------------------------------------------
@@ -99,15 +101,20 @@ int ssie_make_conv(ConvParams& p, const SrcDesc* srcs, int nsrc, int N, int Hv, 
     // barriers and tile boundaries per MFMA
     const int span = (mxy - mny) > (mxx - mnx) ? (mxy - mny) : (mxx - mnx);
     p.th = (si == 1 && Ho >= 16 && Wo >= 16 && ((span <= 2 && ssie_fprop_tile16) || (span <= 8 && ssie_fprop_use_v2))) ? 16 : 8;
-    p.hp_h = (p.th - 1) * si + (mxy - mny) + 1;
-    p.hp_w = (SSIE_TW - 1) * si + (mxx - mnx) + 1;
-    for (int i = 0; i < t.n; ++i) { p.tap_dy[i] = t.dy[i]; p.tap_dx[i] = t.dx[i]; }
     p.wpacked = wpacked; p.Cout = Cout; p.Cout_pad = Cout > 32 ? ssie_round_up(Cout, 64) : 32;
+    // 16 x 32 tiles (wide v2 kernel): 64-channel-multiple outputs, small halo, and at least two tiles per CU
+    p.tw = SSIE_TW;
+    if (ssie_fprop_wide && p.th == 16 && ssie_fprop_use_v2 && span <= 2 && p.Cout_pad % 64 == 0 && Wo >= 32 &&
+        (long)N * ssie_ceil_div(Ho, 16) * ssie_ceil_div(Wo, 32) * (p.Cout_pad / 64) >= 512)
+        p.tw = 32;
+    p.hp_h = (p.th - 1) * si + (mxy - mny) + 1;
+    p.hp_w = (p.tw - 1) * si + (mxx - mnx) + 1;
+    for (int i = 0; i < t.n; ++i) { p.tap_dy[i] = t.dy[i]; p.tap_dx[i] = t.dx[i]; }
     p.out = out; p.out_cstride = out_cstride; p.out_coff = out_coff; p.Hout = Hout; p.Wout = Wout;
     p.so = so; p.py = py; p.px = px;
     p.bias = e.bias; p.act = e.act; p.addsrc = e.addsrc; p.out2 = e.out2; p.mask_y = e.mask_y;
     p.mask_mode = e.mask_y ? e.mask_mode : MASK_NONE; p.accumulate = e.accumulate;
-    p.tiles_y = ssie_ceil_div(Ho, p.th); p.tiles_x = ssie_ceil_div(Wo, SSIE_TW);
+    p.tiles_y = ssie_ceil_div(Ho, p.th); p.tiles_x = ssie_ceil_div(Wo, p.tw);
     p.co_blocks = p.Cout_pad > 32 ? p.Cout_pad / 64 : 1;
     return 0;
 }
@@ -132,6 +139,7 @@ int ssie_make_conv_bf16(ConvParams& p, const SrcDesc* srcs, int nsrc, int N, int
     p.hp_h = (p.th - 1) * si + (mxy - mny) + 1;
     p.hp_w = (SSIE_TW - 1) * si + (mxx - mnx) + 1;
     p.tiles_y = ssie_ceil_div(Ho, p.th);
+    p.tw = SSIE_TW; p.tiles_x = ssie_ceil_div(Wo, SSIE_TW);
     p.out_bf16 = out_bf16;
     return 0;
 }

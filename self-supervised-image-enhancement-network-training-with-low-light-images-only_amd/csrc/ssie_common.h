@@ -61,6 +61,7 @@ struct ConvParams {
     int accumulate;         // out += v instead of out = v
     int tiles_y, tiles_x, co_blocks;
     int th;                 // output tile rows: 8, or 16 for the stride-1 3x3 / 1x1 layers
+    int tw;                 // output tile columns: 16, or 32 for the wide v2 kernel (big 64-channel stride-1 3x3 layers)
     int* tile_counter;      // optional dynamic tile queue (device int, zero before the launch); null = static stride
     int out_bf16;           // bf16 inference kernel only: element type of `out` (addsrc / out2 are always bf16 there)
 };

@@ -46,6 +46,8 @@ def lib():
     L.ssie_op_workspace_bytes.restype = C.c_size_t
     if os.environ.get("SSIE_OVERLAP") is not None:      # dev switch: 0 = slab reductions in launch order on the main stream
         L.ssie_debug_set_overlap(int(os.environ["SSIE_OVERLAP"]))
+    if os.environ.get("SSIE_WIDE") is not None:         # dev switch: 0 = no 16 x 32 tiles
+        L.ssie_debug_set_fprop_wide(int(os.environ["SSIE_WIDE"]))
     if os.environ.get("SSIE_V2_SPLIT") is not None:     # dev switch: 0 = never split a CU between two 4-wave workgroups
         L.ssie_debug_set_fprop_v2_split(int(os.environ["SSIE_V2_SPLIT"]))
     _LIB = L
