@@ -300,6 +300,17 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_v2w_kernel(const ConvParams
     for (int m = 0; m < MT; ++m) {
         pixbase[m] = (2 * wave + (li >> 4)) * p.hp_w + 16 * m + (li & 15);
     }
+    // the wide kernel only runs layers with <= 9 taps (one tap group), so every A-fragment address is tile-invariant:
+    // byte offset inside a halo buffer of (M-tile m, tap t, k-quad 0); k-quad 1 is the same address ^ 32 (slot index ^ 2).
+    // This takes the ~7 address VALU ops per 128-bit fragment read out of the MFMA loop (energy per FLOP).
+    int aaddr[SSIE_TG][MT];
+#pragma unroll
+    for (int t = 0; t < SSIE_TG; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int hp = pixbase[m] + ((int)p.tap_dy[t] - p.min_dy) * p.hp_w + ((int)p.tap_dx[t] - p.min_dx);
+            aaddr[t][m] = t < p.ntaps ? (hp * 4 + (h ^ ssie_swz(hp))) * 16 : 0;
+        }
     const int ngroups = (p.ntaps + SSIE_TG - 1) / SSIE_TG;
     const int nsteps = p.nchunks * ngroups;
     const int total_tiles = p.N * p.tiles_y * p.tiles_x * p.co_blocks;
@@ -399,20 +410,17 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_v2w_kernel(const ConvParams
                 if (more) V2_PREFETCH(nchunk, ng, n, a0, b0, co0, buf ^ 1, a_nxt)                         \
                 else if (ntile < total_tiles) V2_PREFETCH(0, 0, nn, na0, nb0, nco0, buf ^ 1, a_nxt)       \
             }
-            if (!late_prefetch) V2_ISSUE_NEXT
+            V2_ISSUE_NEXT
 
-            const f32x4* As = As0 + a_cur * HP4;
-            const f32x4* Bs = Bs0 + buf * BSZ;
-#define V2_LDFRAG(BF, AF, TL, KQ, OFF)                                                                \
+            const char* Ab = (const char*)(As0 + a_cur * HP4);
+            const f32x4* Bl = Bs0 + buf * BSZ + h * BN + li;          // this lane's column of the weight group
+#define W_LD(BF, AF, TL, KQ)                                                                              \
             {                                                                                             \
-                _Pragma("unroll") for (int c_ = 0; c_ < NT; ++c_)                                         \
-                    BF[c_] = Bs[((TL) * 4 + (KQ) * 2 + h) * BN + c_ * 32 + li];                           \
-                _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_) {                                       \
-                    const int hp_ = pixbase[m_] + (OFF);                                                  \
-                    AF[m_] = As[hp_ * 4 + (((KQ) * 2 + h) ^ ssie_swz(hp_))];                              \
-                }                                                                                         \
+                _Pragma("unroll") for (int c_ = 0; c_ < NT; ++c_) BF[c_] = Bl[((TL) * 4 + (KQ) * 2) * BN + c_ * 32]; \
+                _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_)                                         \
+                    AF[m_] = *(const f32x4*)(Ab + ((KQ) ? (aaddr[TL][m_] ^ 32) : aaddr[TL][m_]));         \
             }
-#define V2_MFMA4(BF, AF)                                                                              \
+#define W_MFMA(BF, AF)                                                                                    \
             _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_)                                             \
             _Pragma("unroll") for (int c_ = 0; c_ < NT; ++c_) {                                           \
                 acc[m_][c_] = MFMA32(AF[m_].x, BF[c_].x, acc[m_][c_]); acc[m_][c_] = MFMA32(AF[m_].y, BF[c_].y, acc[m_][c_]); \
@@ -420,21 +428,18 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_v2w_kernel(const ConvParams
             }
             {
                 f32x4 bX[NT], bY[NT], aX[MT], aY[MT];
-                int off = tapoff[t0];
-                V2_LDFRAG(bX, aX, 0, 0, off)
-                const int pf_at = late_prefetch ? (tg >> 1) : -1;
-                for (int tl = 0; tl < tg; ++tl) {
-                    const int off_next = tapoff[t0 + min(tl + 1, tg - 1)];
-                    V2_LDFRAG(bY, aY, tl, 1, off)
-                    V2_MFMA4(bX, aX)
-                    if (tl == pf_at) V2_ISSUE_NEXT
-                    if (tl + 1 < tg) V2_LDFRAG(bX, aX, tl + 1, 0, off_next)
-                    V2_MFMA4(bY, aY)
-                    off = off_next;
+                W_LD(bX, aX, 0, 0)
+#pragma unroll
+                for (int tl = 0; tl < SSIE_TG; ++tl) {
+                    if (tl >= tg) break;
+                    W_LD(bY, aY, tl, 1)
+                    W_MFMA(bX, aX)
+                    if (tl + 1 < SSIE_TG && tl + 1 < tg) W_LD(bX, aX, (tl + 1 < SSIE_TG ? tl + 1 : 0), 0)
+                    W_MFMA(bY, aY)
                 }
             }
-#undef V2_LDFRAG
-#undef V2_MFMA4
+#undef W_LD
+#undef W_MFMA
 #undef V2_ISSUE_NEXT
             // draw the tile after next from the queue; its value is only needed at the next step's hand-off
             if (tid == 0 && step == 0 && nsteps > 1 && p.tile_counter)
