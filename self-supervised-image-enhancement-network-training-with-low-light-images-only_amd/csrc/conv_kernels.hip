@@ -627,10 +627,27 @@ static int launch_fprop_t(const ConvParams& p, size_t lds, hipStream_t st)
 int ssie_fprop_use_v2 = 1;
 extern "C" void ssie_debug_set_fprop_v2(int v) { ssie_fprop_use_v2 = v; }
 
+static int ssie_launch_fprop_nt1(const ConvParams& p, hipStream_t st)
+{
+    if (p.Cout_pad % 32 || p.ntaps < 1 || p.ntaps > SSIE_MAX_TAPS) return 11;
+    size_t lds = ssie_fprop_lds_bytes(&p, 1);
+    const int na = (p.hp_h * p.hp_w * 4 + 255) / 256;
+    if (lds > 160 * 1024 || na > 9) return 13;
+    if (p.th == 16) return na > 6 ? 16 : launch_fprop_t<1, 6, 16>(p, lds, st);
+    if (p.th != 8) return 17;
+    return na <= 3 ? launch_fprop_t<1, 3, 8>(p, lds, st) : (na <= 6 ? launch_fprop_t<1, 6, 8>(p, lds, st) : launch_fprop_t<1, 9, 8>(p, lds, st));
+}
+
 int ssie_launch_fprop(const ConvParams& p, hipStream_t st)
 {
     if (ssie_fprop_use_v2 && ssie_fprop_v2_ok(p)) return ssie_launch_fprop_v2(p, st);
-    const int nt = (p.Cout_pad % 64 == 0) ? 2 : 1;
+    int nt = (p.Cout_pad % 64 == 0) ? 2 : 1;
+    if (nt == 2 && (long)p.N * p.tiles_y * p.tiles_x * p.co_blocks < 256) {
+        // small launch (batch 1-2): split the 64-channel tiles into 32-channel ones to double the workgroups
+        ConvParams q = p;
+        q.co_blocks = p.Cout_pad / 32;
+        return ssie_launch_fprop_nt1(q, st);
+    }
     if (p.Cout_pad % 32) return 11;
     if (p.ntaps < 1 || p.ntaps > SSIE_MAX_TAPS) return 12;
     size_t lds = ssie_fprop_lds_bytes(&p, nt);

@@ -5,6 +5,8 @@
 #include <string.h>
 
 int ssie_fprop_tile16 = 0;   // tuning knob (tools/): 0 forces 8-row tiles everywhere
+int ssie_fprop_min_tiles16 = 256;   // fewer 16 x 16 tiles than this: 8 x 16 tiles (and 32-channel splits) instead
+extern "C" void ssie_debug_set_fprop_min_tiles16(int v) { ssie_fprop_min_tiles16 = v; }
 int ssie_fprop_wide = 1;     // 1: 16 x 32 tiles (conv_fprop_v2w_kernel) for the big 64-channel stride-1 3x3 layers
 extern "C" void ssie_debug_set_fprop_wide(int v) { ssie_fprop_wide = v; }
 extern "C" void ssie_debug_set_fprop_tile16(int v) { ssie_fprop_tile16 = v; }
@@ -100,7 +102,11 @@ int ssie_make_conv(ConvParams& p, const SrcDesc* srcs, int nsrc, int N, int Hv, 
     // 16-row tiles for the stride-1 layers with a small halo (3x3, 1x1, parity classes): half the weight staging,
     // barriers and tile boundaries per MFMA
     const int span = (mxy - mny) > (mxx - mnx) ? (mxy - mny) : (mxx - mnx);
-    p.th = (si == 1 && Ho >= 16 && Wo >= 16 && ((span <= 2 && ssie_fprop_tile16) || (span <= 8 && ssie_fprop_use_v2))) ? 16 : 8;
+    // ... but only when 16 x 16 tiles still give every CU a workgroup: at batch 1-2 (the reference configs' batch) a
+    // 128 x 128 layer is 64 such tiles, and the 8 x 16 kernel (2-4x the workgroups) finishes it sooner
+    const long tiles16 = (long)N * ssie_ceil_div(Ho, 16) * ssie_ceil_div(Wo, 16) * (Cout > 32 ? ssie_round_up(Cout, 64) / 64 : 1);
+    p.th = (si == 1 && Ho >= 16 && Wo >= 16 && tiles16 >= ssie_fprop_min_tiles16 &&
+            ((span <= 2 && ssie_fprop_tile16) || (span <= 8 && ssie_fprop_use_v2))) ? 16 : 8;
     p.wpacked = wpacked; p.Cout = Cout; p.Cout_pad = Cout > 32 ? ssie_round_up(Cout, 64) : 32;
     // 16 x 32 tiles (wide v2 kernel): 64-channel-multiple outputs, small halo, and at least two tiles per CU
     p.tw = SSIE_TW;
