@@ -21,12 +21,17 @@
 // (s&3) + 8*(s>>2) + 4h, which we simply DEFINE as the h-th key of contraction step s (the order of a sum is free), and
 // V^T is fetched from LDS to match.  No shuffle, no LDS round trip for P.  The two lane halves of a query share the
 // running max (one cross-half exchange per block) and keep separate partial sums, joined once at the end.
-#define AQ_WG 128        // queries per workgroup (4 waves x 32)
-#define AK_ST 64         // keys staged in LDS per iteration
+#define AK_W 64          // keys per wave per iteration (two 32-key blocks)
+#define AK_ST 256        // keys staged in LDS per iteration: the four waves of a workgroup take 64 each
 #define AK_LD 20         // padded LDS row (floats): 16-byte aligned rows, conflict-free 128-bit reads
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// A workgroup = 32 queries of one head; its FOUR waves split the keys (wave w takes keys 64w .. 64w+63 of every staged
+// 256-key slab) and merge their (max, sum, O) states through LDS at the end.  With one wave per 32 queries a 16 384-token
+// image gave only two waves per SIMD - too few to overlap one wave's softmax (VALU, cross-half exchange) with another's
+// MFMAs; the key split quadruples the waves in flight.  Logits are kept in base-2 units (log2(e) folded into the query
+// scale), so the softmax exponentials are bare v_exp_f32.
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, int qs, float* __restrict__ o, int os,
                                                        float* __restrict__ lse, int T, float scale)
 {
@@ -35,10 +40,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, li = lane & 31;
     const int head = blockIdx.y, n = blockIdx.z;
-    const int qi = blockIdx.x * AQ_WG + wave * 32 + li;
+    const int qi = blockIdx.x * 32 + li;
     const float* base = qkv + (size_t)n * T * qs;
+    const float LOG2E = 1.4426950408889634f;
 
-    // B operand of S^T: lane (q, h) supplies Q[q][8h + s] * scale at contraction step s
+    // B operand of S^T: lane (q, h) supplies Q[q][8h + s] * scale * log2(e) at contraction step s
     float qb[8];
     {
         f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0;
@@ -47,17 +53,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
             q1 = *(const f32x4*)(base + (size_t)qi * qs + head * AT_D + 8 * h + 4);
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) { qb[s] = q0[s] * scale; qb[4 + s] = q1[s] * scale; }
+        for (int s = 0; s < 4; ++s) { qb[s] = q0[s] * (scale * LOG2E); qb[4 + s] = q1[s] * (scale * LOG2E); }
     }
     f32x16 oacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
-    float m = -INFINITY, lsum = 0.f;
+    float m = -INFINITY, lsum = 0.f;       // m in base-2 units
 
     for (int k0 = 0; k0 < T; k0 += AK_ST) {
         __syncthreads();
-        {
-            const int r = tid >> 2, c4 = (tid & 3) * 4;
+#pragma unroll
+        for (int it = 0; it < AK_ST * 4 / 256; ++it) {
+            const int id = it * 256 + tid;
+            const int r = id >> 2, c4 = (id & 3) * 4;
             f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
             if (k0 + r < T) {
                 kv = *(const f32x4*)(base + (size_t)(k0 + r) * qs + 64 + head * AT_D + c4);
@@ -67,11 +75,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         }
         __syncthreads();
 #pragma unroll
-        for (int sub = 0; sub < AK_ST / 32; ++sub) {
-            const int kb = k0 + sub * 32;
+        for (int sub = 0; sub < AK_W / 32; ++sub) {
+            const int lr = wave * AK_W + sub * 32;          // first LDS row of this wave's block
+            const int kb = k0 + lr;
             if (kb >= T) break;
             // S^T = K Q^T: A operand lane (key, h) supplies K[key][8h + s]
-            const f32x4 ka0 = *(const f32x4*)&Ks[sub * 32 + li][8 * h], ka1 = *(const f32x4*)&Ks[sub * 32 + li][8 * h + 4];
+            const f32x4 ka0 = *(const f32x4*)&Ks[lr + li][8 * h], ka1 = *(const f32x4*)&Ks[lr + li][8 * h + 4];
             f32x16 st;
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[r] = 0.f;
@@ -89,10 +98,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
             for (int r = 1; r < 16; ++r) mb = fmaxf(mb, st[r]);
             mb = fmaxf(mb, __shfl_xor(mb, 32));
             const float m_new = fmaxf(m, mb);                 // finite: key kb < T is never masked
-            const float alpha = expf(m - m_new);
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
             float ps = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { st[r] = expf(st[r] - m_new); ps += st[r]; }
+            for (int r = 0; r < 16; ++r) { st[r] = __builtin_amdgcn_exp2f(st[r] - m_new); ps += st[r]; }
             lsum = lsum * alpha + ps;
 #pragma unroll
             for (int r = 0; r < 8; ++r) oacc[r] *= alpha;     // rows d < 16 of O^T live in registers 0..7
@@ -100,19 +109,46 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
             // O^T += V^T P^T: step s contracts key rows (s&3) + 8*(s>>2) + 4h
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                const float a = Vs[sub * 32 + (s & 3) + 8 * (s >> 2) + 4 * h][li & 15];
+                const float a = Vs[lr + (s & 3) + 8 * (s >> 2) + 4 * h][li & 15];
                 oacc = MFMA32(a, st[s], oacc);
             }
         }
     }
-    const float ltot = lsum + __shfl_xor(lsum, 32);
-    if (qi < T) {
-        const float inv = 1.f / ltot;
-        float* op = o + ((size_t)n * T + qi) * os + head * AT_D + 4 * h;
-        const f32x4 v0 = {oacc[0] * inv, oacc[1] * inv, oacc[2] * inv, oacc[3] * inv};
-        const f32x4 v1 = {oacc[4] * inv, oacc[5] * inv, oacc[6] * inv, oacc[7] * inv};
-        *(f32x4*)op = v0; *(f32x4*)(op + 8) = v1;
-        if (h == 0) lse[((size_t)n * 4 + head) * T + qi] = m + logf(ltot);
+    // merge the four waves' partial states (a wave that saw no key has m = -inf, l = 0, O = 0)
+    lsum += __shfl_xor(lsum, 32);
+    __syncthreads();
+    float* mg = &Ks[0][0];                   // [3 waves][10][64 lanes] floats = 7.7 KB, inside the staging area
+    if (wave > 0) {
+        float* d = mg + (size_t)(wave - 1) * 10 * 64 + lane;
+        d[0] = m; d[64] = lsum;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) d[(2 + r) * 64] = oacc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float mw[3], lw[3];
+        float mt = m;
+#pragma unroll
+        for (int w = 0; w < 3; ++w) { mw[w] = mg[(size_t)w * 10 * 64 + lane]; lw[w] = mg[(size_t)w * 10 * 64 + 64 + lane]; mt = fmaxf(mt, mw[w]); }
+        const float f0 = __builtin_amdgcn_exp2f(m - mt);
+        float ltot = lsum * f0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) oacc[r] *= f0;
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            const float f = __builtin_amdgcn_exp2f(mw[w] - mt);
+            ltot += lw[w] * f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) oacc[r] += mg[(size_t)w * 10 * 64 + (2 + r) * 64 + lane] * f;
+        }
+        if (qi < T) {
+            const float inv = 1.f / ltot;
+            float* op = o + ((size_t)n * T + qi) * os + head * AT_D + 4 * h;
+            const f32x4 v0 = {oacc[0] * inv, oacc[1] * inv, oacc[2] * inv, oacc[3] * inv};
+            const f32x4 v1 = {oacc[4] * inv, oacc[5] * inv, oacc[6] * inv, oacc[7] * inv};
+            *(f32x4*)op = v0; *(f32x4*)(op + 8) = v1;
+            if (h == 0) lse[((size_t)n * 4 + head) * T + qi] = mt * 0.6931471805599453f + logf(ltot);
+        }
     }
 }
 
@@ -229,7 +265,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
 
 int ssie_launch_attn_fwd(const float* qkv, int qs, float* o, int os, float* lse, int N, int T, hipStream_t st)
 {
-    dim3 grid((T + AQ_WG - 1) / AQ_WG, 4, N);
+    dim3 grid((T + 31) / 32, 4, N);
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, st, qkv, qs, o, os, lse, T, 0.25f);
     return hipGetLastError() == hipSuccess ? 0 : 61;
 }
