@@ -5,3 +5,5 @@
 int ssie_launch_attn_fwd(const float* qkv, int qs, float* o, int os, float* lse, int N, int T, hipStream_t st);
 int ssie_launch_attn_bwd(const float* qkv, int qs, const float* o, const float* go, int os, const float* lse,
                          float* delta, float* gqkv, int N, int T, hipStream_t st);
+// bf16-MFMA forward of the mixed-precision enhance-only path: fp32 qkv in, bf16 output (N*T, os), no lse
+int ssie_launch_attn_fwd_bf16(const float* qkv, int qs, void* o, int os, int N, int T, hipStream_t st);

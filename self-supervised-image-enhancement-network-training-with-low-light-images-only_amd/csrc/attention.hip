@@ -152,6 +152,132 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     }
 }
 
+// bf16-MFMA variant for the mixed-precision enhance-only path (no lse, bf16 output): same transposed-logits scheme with
+// v_mfma_f32_32x32x16_bf16 - S^T is ONE MFMA per 32 x 32 block (K = the 16 head dims) and O^T += V^T P^T two (K = 32 keys).
+// The contraction order over keys is again free: MFMA j, lane half h contracts the keys held by accumulator registers
+// 8j .. 8j+7 of that half, and V^T is staged in LDS already permuted to that order (Vt[block][d][16j + 8h + (r&7)]), so both
+// operands of the second product are single 128-bit reads / register packs.  fp32 softmax and accumulation.
+typedef __bf16 at_bf16x8 __attribute__((ext_vector_type(8)));
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(at_bf16x8, (a)), __builtin_bit_cast(at_bf16x8, (b)), (c), 0, 0, 0)
+__device__ __forceinline__ unsigned at_f2bf(float f) { unsigned u = __float_as_uint(f); u += 0x7fffu + ((u >> 16) & 1u); return u >> 16; }
+__device__ __forceinline__ unsigned at_pack2(float a, float b) { return at_f2bf(a) | (at_f2bf(b) << 16); }
+#define AV_LD 40         // Vt row: 32 bf16 keys padded to 40 (80 B): conflict-free 128-bit reads across the 16 dims
+
+__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const float* __restrict__ qkv, int qs, unsigned short* __restrict__ o, int os, int T, float scale)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short Kh[AK_ST][16];             // [key][dim]
+    __shared__ __attribute__((aligned(16))) unsigned short Vt[AK_ST / 32][16][AV_LD];  // [32-key block][dim][permuted key]
+    __shared__ float mg[3][10][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, li = lane & 31;
+    const int head = blockIdx.y, n = blockIdx.z;
+    const int qi = blockIdx.x * 32 + li;
+    const float* base = qkv + (size_t)n * T * qs;
+    const float LOG2E = 1.4426950408889634f;
+
+    uint4 qb;                                    // B operand of S^T: Q[q][8h .. 8h+7] * scale * log2(e), bf16
+    {
+        f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0;
+        if (qi < T) {
+            q0 = *(const f32x4*)(base + (size_t)qi * qs + head * AT_D + 8 * h);
+            q1 = *(const f32x4*)(base + (size_t)qi * qs + head * AT_D + 8 * h + 4);
+        }
+        const float c = scale * LOG2E;
+        qb = make_uint4(at_pack2(q0[0] * c, q0[1] * c), at_pack2(q0[2] * c, q0[3] * c), at_pack2(q1[0] * c, q1[1] * c), at_pack2(q1[2] * c, q1[3] * c));
+    }
+    f32x16 oacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+    float m = -INFINITY, lsum = 0.f;
+
+    for (int k0 = 0; k0 < T; k0 += AK_ST) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < AK_ST * 4 / 256; ++it) {
+            const int id = it * 256 + tid;
+            const int r = id >> 2, c4 = (id & 3) * 4;           // key row r of the slab, dims c4 .. c4+3
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
+            if (k0 + r < T) {
+                kv = *(const f32x4*)(base + (size_t)(k0 + r) * qs + 64 + head * AT_D + c4);
+                vv = *(const f32x4*)(base + (size_t)(k0 + r) * qs + 128 + head * AT_D + c4);
+            }
+            *(uint2*)&Kh[r][c4] = make_uint2(at_pack2(kv[0], kv[1]), at_pack2(kv[2], kv[3]));
+            const int key = r & 31, blk = r >> 5;
+            const int rr = (key & 3) + 4 * (key >> 3), hh = (key >> 2) & 1;
+            const int pos = (rr >> 3) * 16 + hh * 8 + (rr & 7);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Vt[blk][c4 + e][pos] = (unsigned short)at_f2bf(vv[e]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < AK_W / 32; ++sub) {
+            const int lr = wave * AK_W + sub * 32;
+            const int kb = k0 + lr;
+            if (kb >= T) break;
+            const uint4 ka = *(const uint4*)&Kh[lr + li][8 * h];
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+            st = MFMA_BF16(ka, qb, st);
+            if (kb + 32 > T) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kb + (r & 3) + 8 * (r >> 2) + 4 * h >= T) st[r] = -INFINITY;
+            }
+            float mb = st[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mb = fmaxf(mb, st[r]);
+            mb = fmaxf(mb, __shfl_xor(mb, 32));
+            const float m_new = fmaxf(m, mb);
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[r] = __builtin_amdgcn_exp2f(st[r] - m_new); ps += st[r]; }
+            lsum = lsum * alpha + ps;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) oacc[r] *= alpha;
+            m = m_new;
+            const int blk = lr >> 5;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint4 va = *(const uint4*)&Vt[blk][li & 15][j * 16 + h * 8];
+                const uint4 pb = make_uint4(at_pack2(st[8 * j + 0], st[8 * j + 1]), at_pack2(st[8 * j + 2], st[8 * j + 3]),
+                                            at_pack2(st[8 * j + 4], st[8 * j + 5]), at_pack2(st[8 * j + 6], st[8 * j + 7]));
+                oacc = MFMA_BF16(va, pb, oacc);
+            }
+        }
+    }
+    lsum += __shfl_xor(lsum, 32);
+    if (wave > 0) {
+        mg[wave - 1][0][lane] = m; mg[wave - 1][1][lane] = lsum;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) mg[wave - 1][2 + r][lane] = oacc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float mt = m;
+#pragma unroll
+        for (int w = 0; w < 3; ++w) mt = fmaxf(mt, mg[w][0][lane]);
+        const float f0 = __builtin_amdgcn_exp2f(m - mt);
+        float ltot = lsum * f0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) oacc[r] *= f0;
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            const float f = __builtin_amdgcn_exp2f(mg[w][0][lane] - mt);
+            ltot += mg[w][1][lane] * f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) oacc[r] += mg[w][2 + r][lane] * f;
+        }
+        if (qi < T) {
+            const float inv = 1.f / ltot;
+            unsigned short* op = o + ((size_t)n * T + qi) * os + head * AT_D + 4 * h;
+            *(uint2*)op = make_uint2(at_pack2(oacc[0] * inv, oacc[1] * inv), at_pack2(oacc[2] * inv, oacc[3] * inv));
+            *(uint2*)(op + 8) = make_uint2(at_pack2(oacc[4] * inv, oacc[5] * inv), at_pack2(oacc[6] * inv, oacc[7] * inv));
+        }
+    }
+}
+
 // dQ: one thread per query row.  p_ij = exp(s_ij - lse_i), dS = p (dP - delta), dQ_i = scale * sum_j dS_ij K_j.
 // delta_i = sum_j p_ij dP_ij / sum_j p_ij is accumulated from the SAME p and dP that form dS (first sweep), so
 // sum_j dS_ij cancels to rounding like torch's softmax backward does; the cheaper dO.O form leaves an error
@@ -268,6 +394,14 @@ int ssie_launch_attn_fwd(const float* qkv, int qs, float* o, int os, float* lse,
     dim3 grid((T + 31) / 32, 4, N);
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, st, qkv, qs, o, os, lse, T, 0.25f);
     return hipGetLastError() == hipSuccess ? 0 : 61;
+}
+
+// qkv fp32 (N*T, qs); o bf16 (N*T, os)
+int ssie_launch_attn_fwd_bf16(const float* qkv, int qs, void* o, int os, int N, int T, hipStream_t st)
+{
+    dim3 grid((T + 31) / 32, 4, N);
+    hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid, dim3(256), 0, st, qkv, qs, (unsigned short*)o, os, T, 0.25f);
+    return hipGetLastError() == hipSuccess ? 0 : 63;
 }
 
 int ssie_launch_attn_bwd(const float* qkv, int qs, const float* o, const float* go, int os, const float* lse,

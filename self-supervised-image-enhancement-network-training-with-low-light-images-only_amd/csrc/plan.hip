@@ -407,11 +407,11 @@ int build_illum_fwd(Builder& b, std::vector<Fn>& ops)
     if (!b.dry) {
         const float* qkv = pl.buf("qkv"); float* ao = pl.buf("ao"); float* lse = pl.buf("lse");
         const int N = pl.N, T = H8 * W8;
-        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_attn_fwd(qkv, 192, ao, 64, lse, N, T, st); }, K_ATTN, 4.0 * N * 4 * (double)T * T * 16));
         if (b.h16) {
-            float* aoh = pl.buf("aoh"); const long ne = (long)N * T * 64;
-            ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_to_bf16(ao, aoh, ne, st); }));
-        }
+            float* aoh = pl.buf("aoh");
+            ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_attn_fwd_bf16(qkv, 192, aoh, 64, N, T, st); }, K_ATTN, 4.0 * N * 4 * (double)T * T * 16));
+        } else
+            ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_attn_fwd(qkv, 192, ao, 64, lse, N, T, st); }, K_ATTN, 4.0 * N * 4 * (double)T * T * 16));
     }
     CK(b.conv(ops, layer(pl, i + "attn.ff_linear1"), {b.src("ao", 64, H8, W8)}, H8, W8, 1, "f1", ACT_RELU));
     CK(b.conv(ops, layer(pl, i + "attn.ff_linear2"), {b.src("f1", 64, H8, W8)}, H8, W8, 1, "t3", ACT_NONE, "a3"));
