@@ -510,24 +510,37 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 // per-channel sums of G over all pixels (bias gradient of the transposed conv), two-stage & deterministic.
-// Stage 1: block = 64 channels x 4 pixel lanes, coalesced 256-byte rows; stage 2: one block per channel reduces the
-// per-block partials with 256 threads.
+// Stage 1: a thread owns one channel quad (float4) and every (256 / quads)-th pixel of the block's range, with four
+// independent loads in flight (the plain one-load-per-iteration loop was latency-bound at ~1 TB/s); fixed-order LDS
+// tree over the pixel lanes; stage 2: one block per channel reduces the per-block partials with 256 threads.
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ g, long npix, int cstride, int coff, int C,
                                       float* __restrict__ partial /*[gridDim.x][C]*/)
 {
-    __shared__ float red[4][64];
-    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    __shared__ f32x4 red[256];
+    const int cq = (C + 3) / 4;                      // channel quads (<= 64); coff and cstride are multiples of 4
+    const int lanes = 256 / cq;                      // pixel lanes
+    const int q = threadIdx.x % cq, pl = threadIdx.x / cq;
     const long per = (npix + gridDim.x - 1) / gridDim.x;
     const long beg = (long)blockIdx.x * per, end = min(beg + per, npix);
-    for (int c0 = 0; c0 < C; c0 += 64) {
-        const int c = c0 + cl;
-        float sum = 0.f;
-        if (c < C)
-            for (long px = beg + pl; px < end; px += 4) sum += g[px * cstride + coff + c];
-        red[pl][cl] = sum;
-        __syncthreads();
-        if (pl == 0 && c < C) partial[(size_t)blockIdx.x * C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
-        __syncthreads();
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if (pl < lanes) {
+        const float* gp = g + coff + 4 * q;
+        long px = beg + pl;
+        for (; px + 3L * lanes < end; px += 4L * lanes) {
+            const f32x4 v0 = *(const f32x4*)(gp + px * cstride), v1 = *(const f32x4*)(gp + (px + lanes) * cstride);
+            const f32x4 v2 = *(const f32x4*)(gp + (px + 2L * lanes) * cstride), v3 = *(const f32x4*)(gp + (px + 3L * lanes) * cstride);
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+        }
+        for (; px < end; px += lanes) s0 += *(const f32x4*)(gp + px * cstride);
+    }
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (pl == 0) {
+        f32x4 t = red[q];
+        for (int l = 1; l < lanes; ++l) t += red[l * cq + q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * q + e < C) partial[(size_t)blockIdx.x * C + 4 * q + e] = t[e];
     }
 }
 

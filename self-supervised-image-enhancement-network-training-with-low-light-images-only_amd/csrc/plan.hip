@@ -343,7 +343,7 @@ struct Builder {
         const BufInfo& gb = pl.bi(g);
         const float* gp = pl.buf(g); float* part = pl.ws + pl.partial_off; float* db = pl.G + L.b;
         const long npix = (long)gb.N * gb.H * gb.W; const int cs = gb.cs, C = L.cout;
-        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_colsum(gp, npix, cs, g_coff, C, part, 256, db, 1, st); }, K_COLSUM));
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_colsum(gp, npix, cs, g_coff, C, part, C <= 128 ? 512 : 256, db, 1, st); }, K_COLSUM));
     }
 
     void mask_axpy(std::vector<Fn>& ops, const char* src, const char* y, int mode, const char* dst, int C, int accumulate)
