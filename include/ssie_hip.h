@@ -134,7 +134,8 @@ int ssie_plan_enhance_fwd_bf16(void* plan, const float* x, const long* strides4,
 
 /* compute_loss (+ loss.backward() when with_backward != 0): model.py:544-575, :315.  Writes "scalars";
  * with_backward also zeroes and fills the flat gradient buffer (zero_grad, model.py:313).
- * The Fourier term needs power-of-two H, W with H*(W+1)*8 bytes <= 160 KiB LDS (SSIE_E_SHAPE otherwise). */
+ * The Fourier term keeps one H x (W+1) complex plane in LDS (<= 160 KiB: up to 128 x 128; SSIE_E_SHAPE otherwise):
+ * power-of-two sizes take the radix-2 path, other sizes (<= 192 per side) a direct DFT. */
 int ssie_plan_loss_fwd_bwd(void* plan, const float* x, const long* strides4, int with_backward, void* stream);
 
 /* one compute_loss+backward with a HIP event after every launch: device milliseconds, algorithmic FLOPs and

@@ -81,6 +81,39 @@ __device__ __forceinline__ void fft_pass(float2* z, const float2* tw, int logM, 
     }
 }
 
+// Sizes that are not powers of two: plain O(n^2) DFT of every line, in place.  One wave owns a whole line: lane j (+64q)
+// accumulates output bin j over all inputs (every lane reads the same input element - an LDS broadcast), and the wave writes
+// the line back only after it has consumed it, so no second buffer is needed.  tw[t] = exp(-2 pi i t / n), n entries; the
+// twiddle index (j*k) mod n is advanced incrementally.  ~25x the work of the radix-2 path, still far from dominating a step.
+template <bool INVERSE>
+__device__ __forceinline__ void dft_pass(float2* z, const float2* tw, int n, int lines, int es, int ls, int tid)
+{
+    constexpr int Q = 3;                              // outputs per lane: n <= 192
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int line = wave; line < lines; line += FFT_THREADS / 64) {
+        float2* zl = z + line * ls;
+        float2 acc[Q];
+        int idx[Q], jj[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { acc[q] = make_float2(0.f, 0.f); idx[q] = 0; jj[q] = (lane + 64 * q) % n; }
+        for (int k = 0; k < n; ++k) {
+            const float2 v = zl[k * es];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                float2 w = tw[idx[q]];
+                if (INVERSE) w.y = -w.y;
+                const float2 t = cmul(v, w);
+                acc[q].x += t.x; acc[q].y += t.y;
+                idx[q] += jj[q]; if (idx[q] >= n) idx[q] -= n;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+            if (lane + 64 * q < n) zl[(lane + 64 * q) * es] = acc[q];
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(FFT_THREADS) void fft_loss_kernel(const FftParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -91,13 +124,20 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_loss_kernel(const FftParams p
     if (n >= p.N) { if (threadIdx.x == 0) p.partials[b] = 0.f; return; }
     const int H = p.H, W = p.W, LS = W + 1, tid = threadIdx.x;
     const int M = H > W ? H : W;
+    const bool pow2 = p.logH >= 0;               // radix-2 path; otherwise the direct DFT with per-axis twiddle tables
     float2* z = (float2*)smem_f;                 // [H][W+1]
-    float2* tw = z + H * LS;                     // [M/2]  exp(-2 pi i t / M)
-    float* red = (float*)(tw + (M >> 1));        // [FFT_THREADS/64]
+    float2* tw = z + H * LS;                     // pow2: [M/2] exp(-2 pi i t / M);  generic: [W] for rows, then [H] for columns
+    float2* twc = tw + W;
+    float* red = (float*)(tw + (pow2 ? (M >> 1) : (H + W)));        // [FFT_THREADS/64]
 
-    for (int t = tid; t < (M >> 1); t += FFT_THREADS) {
-        float sn, cs; sincospif(-2.0f * (float)t / (float)M, &sn, &cs);
-        tw[t] = make_float2(cs, sn);
+    if (pow2) {
+        for (int t = tid; t < (M >> 1); t += FFT_THREADS) {
+            float sn, cs; sincospif(-2.0f * (float)t / (float)M, &sn, &cs);
+            tw[t] = make_float2(cs, sn);
+        }
+    } else {
+        for (int t = tid; t < W; t += FFT_THREADS) { float sn, cs; sincospif(-2.0f * (float)t / (float)W, &sn, &cs); tw[t] = make_float2(cs, sn); }
+        for (int t = tid; t < H; t += FFT_THREADS) { float sn, cs; sincospif(-2.0f * (float)t / (float)H, &sn, &cs); twc[t] = make_float2(cs, sn); }
     }
     const size_t base = (size_t)n * H * W;
     for (int id = tid; id < H * W; id += FFT_THREADS) {
@@ -106,18 +146,24 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_loss_kernel(const FftParams p
     }
     __syncthreads();
     const int logM = p.logH > p.logW ? p.logH : p.logW;
-    fft_pass<false>(z, tw, logM, W, p.logW, H, p.logH, 1, LS, tid);      // rows
-    fft_pass<false>(z, tw, logM, H, p.logH, W, p.logW, LS, 1, tid);      // columns
+    if (pow2) {
+        fft_pass<false>(z, tw, logM, W, p.logW, H, p.logH, 1, LS, tid);      // rows
+        fft_pass<false>(z, tw, logM, H, p.logH, W, p.logW, LS, 1, tid);      // columns
+    } else {
+        dft_pass<false>(z, tw, W, H, 1, LS, tid);
+        dft_pass<false>(z, twc, H, W, LS, 1, tid);
+    }
 
     // pointwise: loss and g_Z per conjugate pair {k, -k}
     float lsum = 0.f;
     for (int id = tid; id < H * W; id += FFT_THREADS) {
         const int ky = id / W, kx = id - ky * W;
-        const int qy = (H - ky) & (H - 1), qx = (W - kx) & (W - 1);
+        const int qy = ky ? H - ky : 0, qx = kx ? W - kx : 0;
         const int idm = qy * W + qx;
         if (id > idm) continue;
-        const int pk = (int)(__brev((unsigned)ky) >> (32 - p.logH)) * LS + (int)(__brev((unsigned)kx) >> (32 - p.logW));
-        const int pm = (int)(__brev((unsigned)qy) >> (32 - p.logH)) * LS + (int)(__brev((unsigned)qx) >> (32 - p.logW));
+        // position of bin (ky, kx) in the plane: bit-reversed after the radix-2 DIF passes, natural after the direct DFT
+        const int pk = pow2 ? (int)(__brev((unsigned)ky) >> (32 - p.logH)) * LS + (int)(__brev((unsigned)kx) >> (32 - p.logW)) : ky * LS + kx;
+        const int pm = pow2 ? (int)(__brev((unsigned)qy) >> (32 - p.logH)) * LS + (int)(__brev((unsigned)qx) >> (32 - p.logW)) : qy * LS + qx;
         const float2 Zk = z[pk], Zm = z[pm];
         const float2 Fx = make_float2(0.5f * (Zk.x + Zm.x), 0.5f * (Zk.y - Zm.y));
         const float2 Fs = make_float2(0.5f * (Zk.y + Zm.y), -0.5f * (Zk.x - Zm.x));
@@ -132,8 +178,13 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_loss_kernel(const FftParams p
         if (id != idm) z[pm] = Gm;
     }
     __syncthreads();
-    fft_pass<true>(z, tw, logM, H, p.logH, W, p.logW, LS, 1, tid);       // columns (bit-reversed in, natural out)
-    fft_pass<true>(z, tw, logM, W, p.logW, H, p.logH, 1, LS, tid);       // rows
+    if (pow2) {
+        fft_pass<true>(z, tw, logM, H, p.logH, W, p.logW, LS, 1, tid);       // columns (bit-reversed in, natural out)
+        fft_pass<true>(z, tw, logM, W, p.logW, H, p.logH, 1, LS, tid);       // rows
+    } else {
+        dft_pass<true>(z, twc, H, W, LS, 1, tid);
+        dft_pass<true>(z, tw, W, H, 1, LS, tid);
+    }
     for (int id = tid; id < H * W; id += FFT_THREADS) {
         const int h = id / W, w = id - h * W;
         p.gS[(base + id) * p.s_cs + c] += z[h * LS + w].x;
@@ -151,20 +202,26 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_loss_kernel(const FftParams p
 
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
+static bool is_pow2(int v) { return v >= 2 && !(v & (v - 1)); }
+
+// 1: radix-2 path (power-of-two H and W), 2: direct-DFT path (any H, W <= 192), 0: the plane does not fit the 160 KiB LDS
 int ssie_fft_supported(int H, int W)
 {
-    if (H < 2 || W < 2 || (H & (H - 1)) || (W & (W - 1))) return 0;
-    size_t lds = (size_t)H * (W + 1) * 8 + (size_t)(H > W ? H : W) * 4 + 64;
-    return lds <= 160 * 1024;
+    if (H < 2 || W < 2) return 0;
+    const bool p2 = is_pow2(H) && is_pow2(W);
+    if (!p2 && (H > 192 || W > 192)) return 0;
+    size_t lds = (size_t)H * (W + 1) * 8 + (p2 ? (size_t)(H > W ? H : W) * 4 : (size_t)(H + W) * 8) + 64;
+    return lds <= 160 * 1024 ? (p2 ? 1 : 2) : 0;
 }
 
 int ssie_fft_grid(int N, int B) { return 8 * ((N + 7) / 8) * B; }
 
 int ssie_launch_fft_loss(const FftParams& p, hipStream_t st)
 {
-    if (!ssie_fft_supported(p.H, p.W)) return 51;
+    const int kind = ssie_fft_supported(p.H, p.W);
+    if (!kind || (kind == 1) != (p.logH >= 0)) return 51;
     const int M = p.H > p.W ? p.H : p.W;
-    size_t lds = (size_t)p.H * (p.W + 1) * 8 + (size_t)(M / 2) * 8 + 64;
+    size_t lds = (size_t)p.H * (p.W + 1) * 8 + (kind == 1 ? (size_t)(M / 2) * 8 : (size_t)(p.H + p.W) * 8) + 64;
     static bool set = false;
     if (!set) { hipFuncSetAttribute((const void*)fft_loss_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
     hipLaunchKernelGGL(fft_loss_kernel, dim3(ssie_fft_grid(p.N, p.B)), dim3(FFT_THREADS), lds, st, p);

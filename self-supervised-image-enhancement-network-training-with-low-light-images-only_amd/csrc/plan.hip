@@ -578,7 +578,8 @@ int build_all(Plan& pl, bool dry)
         ops.push_back(Fn([lp, nblk](hipStream_t st) { return ssie_launch_loss_direct(lp, nblk, st); }, K_LOSS));
         FftParams fp; memset(&fp, 0, sizeof(fp));
         fp.x = lp.x; fp.x_cs = lp.x_cs; fp.S = lp.S; fp.s_cs = lp.s_cs; fp.gS = lp.gS; fp.mask = (const uint8_t*)(pl.ws + pl.mask_off);
-        fp.N = N; fp.B = B; fp.H = H; fp.W = W; fp.logH = (int)lround(log2((double)H)); fp.logW = (int)lround(log2((double)W));
+        fp.N = N; fp.B = B; fp.H = H; fp.W = W; if (ssie_fft_supported(H, W) == 1) { fp.logH = (int)lround(log2((double)H)); fp.logW = (int)lround(log2((double)W)); }
+        else { fp.logH = -1; fp.logW = -1; }          // direct-DFT path (sizes that are not powers of two)
         fp.scale_g = (float)(pl.coefs[4] / (n * c * h * w)); fp.inv_n0 = lp.inv_n0; fp.partials = pl.ws + pl.fpart_off;
         ops.push_back(Fn([fp](hipStream_t st) { return ssie_launch_fft_loss(fp, st); }, K_FFT));
         const float* lpart = pl.ws + pl.lpart_off; const float* fpart = pl.ws + pl.fpart_off; float* scal = pl.ws + pl.scal_off;

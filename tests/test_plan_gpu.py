@@ -24,6 +24,8 @@ CASES = {
     "b8_32x64": (3, 8, 32, 64, O.JYU_COEFS),
     "b31_128": (1, 31, 128, 128, O.JYU_COEFS),       # BASELINE.json configs[1] geometry (one patch of the bench batch)
     "b256_64": (1, 256, 64, 64, O.JYU_COEFS),        # BASELINE.json configs[2]: 256-band cubes
+    "b8_24x40": (2, 8, 24, 40, O.JYU_COEFS),         # patch size that is not a power of two: direct-DFT Fourier loss
+    "b5_96": (1, 5, 96, 96, O.DEFAULT_COEFS),
 }
 GRAD_FLOOR = {"b256_64": 5e-3}     # 256 bands: cotangent noise 5-7e-2, deep-layer gradients see ~3e-3 of it
 
