@@ -8,7 +8,9 @@ int ssie_fprop_tile16 = 0;   // tuning knob (tools/): 0 forces 8-row tiles every
 int ssie_fprop_min_tiles16 = 256;   // fewer 16 x 16 tiles than this: 8 x 16 tiles (and 32-channel splits) instead
 extern "C" void ssie_debug_set_fprop_min_tiles16(int v) { ssie_fprop_min_tiles16 = v; }
 int ssie_fprop_wide = 1;     // 1: 16 x 32 tiles (conv_fprop_v2w_kernel) for the big 64-channel stride-1 3x3 layers
+int ssie_fprop_wide_min_tiles = 512;   // ... when the launch has at least this many of them (tests set 1 to force the kernel)
 extern "C" void ssie_debug_set_fprop_wide(int v) { ssie_fprop_wide = v; }
+extern "C" void ssie_debug_set_fprop_wide_min_tiles(int v) { ssie_fprop_wide_min_tiles = v; }
 extern "C" void ssie_debug_set_fprop_tile16(int v) { ssie_fprop_tile16 = v; }
 
 // ---------------------------------------------------------------------------------------------
@@ -111,7 +113,7 @@ int ssie_make_conv(ConvParams& p, const SrcDesc* srcs, int nsrc, int N, int Hv, 
     // 16 x 32 tiles (wide v2 kernel): 64-channel-multiple outputs, small halo, and at least two tiles per CU
     p.tw = SSIE_TW;
     if (ssie_fprop_wide && p.th == 16 && ssie_fprop_use_v2 && span <= 2 && p.Cout_pad % 64 == 0 && Wo >= 32 &&
-        (long)N * ssie_ceil_div(Ho, 16) * ssie_ceil_div(Wo, 32) * (p.Cout_pad / 64) >= 512)
+        (long)N * ssie_ceil_div(Ho, 16) * ssie_ceil_div(Wo, 32) * (p.Cout_pad / 64) >= ssie_fprop_wide_min_tiles)
         p.tw = 32;
     p.hp_h = (p.th - 1) * si + (mxy - mny) + 1;
     p.hp_w = (p.tw - 1) * si + (mxx - mnx) + 1;

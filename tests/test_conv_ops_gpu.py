@@ -20,6 +20,20 @@ def H():
     return hostlib
 
 
+@pytest.fixture(autouse=True, params=["heuristic", "tile16x16", "tile16x32"])
+def kernel_mode(H, request):
+    """The launch heuristics pick 8x16 tiles (register-staged kernel) for launches as small as these tests; the two forced
+    modes run the same cases through the DMA kernels the bench-size layers use: 16x16 tiles (conv_fprop_v2_kernel) and
+    16x32 tiles (conv_fprop_v2w_kernel, where eligible: stride 1, <= 9 taps, 64-multiple Cout, Wo >= 32)."""
+    L = H.lib()
+    if request.param != "heuristic":
+        L.ssie_debug_set_fprop_min_tiles16(0)
+        L.ssie_debug_set_fprop_wide_min_tiles(1 if request.param == "tile16x32" else 1 << 30)
+    yield request.param
+    L.ssie_debug_set_fprop_min_tiles16(256)
+    L.ssie_debug_set_fprop_wide_min_tiles(512)
+
+
 def rnd(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return (torch.rand(*shape, generator=g, dtype=torch.float64) * 2 - 1) * scale
@@ -53,6 +67,9 @@ def close(got, ref, tol=TOL):
     (5, 32, 3, 1, 16, 16, 1),
     (5, 64, 9, 1, 24, 16, 0),
     (64, 192, 1, 1, 8, 32, 0),
+    (64, 64, 3, 1, 32, 64, 1),
+    (96, 64, 3, 1, 20, 40, 0),
+    (128, 128, 3, 1, 16, 48, 1),
 ])
 def test_conv2d_fwd(H, cin, cout, k, stride, h, w, act):
     n = 2

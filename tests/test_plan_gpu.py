@@ -53,9 +53,25 @@ def rel_l2(a, b):
     return (a.double() - b.double()).norm().item() / max(b.double().norm().item(), 1e-30)
 
 
+@pytest.fixture(params=[None, "dma_kernels"])
+def forced_kernels(pkg, request):
+    """None = launch heuristics (8x16 tiles at these small batches).  "dma_kernels" forces the kernels the bench-size
+    layers run - 16x16 and, where eligible, 16x32 tiles (conv_fprop_v2_kernel / conv_fprop_v2w_kernel) - through the same
+    parity cases, so the whole fwd + bwd chain is checked on them too."""
+    L = pkg[0].lib()
+    if request.param:
+        L.ssie_debug_set_fprop_min_tiles16(0)
+        L.ssie_debug_set_fprop_wide_min_tiles(1)
+    yield request.param
+    L.ssie_debug_set_fprop_min_tiles16(256)
+    L.ssie_debug_set_fprop_wide_min_tiles(512)
+
+
 @pytest.mark.parametrize("case", list(CASES))
-def test_stagewise_parity(pkg, case):
+def test_stagewise_parity(pkg, case, forced_kernels):
     H, _ = pkg
+    if forced_kernels and case in ("b5_16", "b256_64", "b5_96"):
+        pytest.skip("forced-kernel variant runs on the mid-size cases only (time)")
     n, bands, h, w, coefs = CASES[case]
     plan, table, flat, gflat, P = build_plan(H, n, bands, h, w, coefs)
     x = O.synthetic_patches(n, bands, h, w)
