@@ -493,7 +493,9 @@ bool ssie_fprop_v2_ok(const ConvParams& p)
 }
 
 static int g_v2_split = 1;      // ssie_debug_set_fprop_v2_split: 0 = always one 8-wave workgroup per CU
+static int g_v2_split_min_tiles = 1024;   // ... for launches with at least this many 32-channel tiles (tests set 1)
 extern "C" void ssie_debug_set_fprop_v2_split(int on) { g_v2_split = on; }
+extern "C" void ssie_debug_set_fprop_v2_split_min_tiles(int v) { g_v2_split_min_tiles = v; }
 
 template <int NT, int NA2, int NW>
 static int launch_v2_t(const ConvParams& p, size_t lds, hipStream_t st)
@@ -525,7 +527,7 @@ int ssie_launch_fprop_v2(const ConvParams& p, hipStream_t st)
         const size_t lds1 = ssie_fprop_v2_lds_bytes(p, 1);
         const int na4 = (p.hp_h * p.hp_w * 4 + 255) / 256;
         const size_t tiles32 = (size_t)p.N * p.tiles_y * p.tiles_x * (p.Cout_pad / 32);
-        if (g_v2_split && nt == 1 && 2 * (lds1 + 256) <= 160 * 1024 && na4 <= 6 && tiles32 >= 1024) {
+        if (g_v2_split && nt == 1 && 2 * (lds1 + 256) <= 160 * 1024 && na4 <= 6 && tiles32 >= (size_t)g_v2_split_min_tiles) {
             ConvParams q = p;
             q.co_blocks = p.Cout_pad / 32;
             return launch_v2_t<1, 6, 4>(q, lds1, st);

@@ -29,9 +29,11 @@ def kernel_mode(H, request):
     if request.param != "heuristic":
         L.ssie_debug_set_fprop_min_tiles16(0)
         L.ssie_debug_set_fprop_wide_min_tiles(1 if request.param == "tile16x32" else 1 << 30)
+        L.ssie_debug_set_fprop_v2_split_min_tiles(1 if request.param == "tile16x32" else 1 << 30)   # 32-channel layers: two 4-wave workgroups per CU
     yield request.param
     L.ssie_debug_set_fprop_min_tiles16(256)
     L.ssie_debug_set_fprop_wide_min_tiles(512)
+    L.ssie_debug_set_fprop_v2_split_min_tiles(1024)
 
 
 def rnd(*shape, seed=0, scale=1.0):

@@ -62,9 +62,11 @@ def forced_kernels(pkg, request):
     if request.param:
         L.ssie_debug_set_fprop_min_tiles16(0)
         L.ssie_debug_set_fprop_wide_min_tiles(1)
+        L.ssie_debug_set_fprop_v2_split_min_tiles(1)
     yield request.param
     L.ssie_debug_set_fprop_min_tiles16(256)
     L.ssie_debug_set_fprop_wide_min_tiles(512)
+    L.ssie_debug_set_fprop_v2_split_min_tiles(1024)
 
 
 @pytest.mark.parametrize("case", list(CASES))
