@@ -265,7 +265,14 @@ INST_FPROP(1, 6, 16) INST_FPROP(2, 6, 16)
 // Each workgroup owns a (ci block, co block, tap group) and a slice of the position tiles; it keeps
 // up to 9 taps x 32x32 accumulators per wave in registers and writes ONE partial slab at the end.
 // ---------------------------------------------------------------------------------------------
-template <int CIB, int COB, int NU>
+// SW selects the K loop: 0 = generic (any tap list / stride; K pairs = horizontal neighbours, one LDS read per MFMA);
+// 1 / 2 = SLIDING WINDOW for stride-1 groups of 9 taps that form a 3 x 3 block (SW = 1) or one row of a 9 x 9 kernel
+// (SW = 2): the K pair is a VERTICAL pair of positions (lane half h takes row 2*rp + h) and the loop walks along the row,
+// so the x value of halo column c serves tap dx at position c - dx: a circular register window takes ONE new LDS read
+// per tap row and step instead of one per tap - 4 (3 x 3) or 2 (1 x 9) reads per 9 MFMAs instead of 10, with
+// compile-time LDS offsets (no address arithmetic in the loop).  The fp32 MFMA kernels are limited by energy per FLOP
+// (DESIGN.md 3.1), and LDS reads were this kernel's largest non-MFMA term.
+template <int CIB, int COB, int NU, int SW>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -385,6 +392,31 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         // MFMA K loop over position pairs (this wave's share: kp = wsub, wsub + WSPLIT, ...)
         // (a register-ping-pong software pipeline of this loop cuts its cycles by 30 % in isolation but the clock and the
         //  co-resident workgroup's staging give all of it back: slower by 2-4 % in wall time, tools/stamp_wgrad.py)
+        if constexpr (SW != 0) {
+            constexpr int NDY = SW == 1 ? 3 : 1, NDX = SW == 1 ? 3 : 9;
+            static_assert(NU == 9, "sliding-window loop: groups of 9 taps");
+            for (int rp = wsub; rp < p.th / 2; rp += WSPLIT) {
+                const int row = 2 * rp + h;
+                const float* xr = Xs + row * p.hp_w * CIB + mi * 32 + li;       // halo (row + d, column c) = xr[(d*hp_w + c)*CIB]
+                const float* gr = Gs + row * SSIE_TW * COB + ni * 32 + li;
+                const int rstr = p.hp_w * CIB;
+                float win[NDY][NDX];                                            // win[d][c % NDX] = halo column c of tap row d
+#pragma unroll
+                for (int d = 0; d < NDY; ++d)
+#pragma unroll
+                    for (int c = 0; c < NDX - 1; ++c) win[d][c] = xr[d * rstr + c * CIB];
+#pragma unroll
+                for (int x = 0; x < SSIE_TW; ++x) {
+#pragma unroll
+                    for (int d = 0; d < NDY; ++d) win[d][(x + NDX - 1) % NDX] = xr[d * rstr + (x + NDX - 1) * CIB];
+                    const float b = gr[x * COB];
+#pragma unroll
+                    for (int d = 0; d < NDY; ++d)
+#pragma unroll
+                        for (int c = 0; c < NDX; ++c) acc[d * NDX + c] = MFMA32(win[d][(x + c) % NDX], b, acc[d * NDX + c]);
+                }
+            }
+        } else {
         const int npair = PT / 2;
         for (int kp = wsub; kp < npair; kp += WSPLIT) {
             const int pix = 2 * kp + h;
@@ -395,6 +427,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
                 const float a = Xs[xbase + toff[u]];
                 acc[u] = MFMA32(a, b, acc[u]);
             }
+        }
         }
         WST(7);
 #ifdef SSIE_STAMP
@@ -455,11 +488,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 #undef WST
 }
 
-#define INST_WGRAD(CI, CO, NU) template __global__ void conv_wgrad_kernel<CI, CO, NU>(const WgradParams);
+#define INST_WGRAD(CI, CO, NU) template __global__ void conv_wgrad_kernel<CI, CO, NU, 0>(const WgradParams);
 INST_WGRAD(64, 64, 9) INST_WGRAD(64, 64, 1)
 INST_WGRAD(32, 64, 9) INST_WGRAD(32, 64, 1)
 INST_WGRAD(64, 32, 9) INST_WGRAD(64, 32, 1)
 INST_WGRAD(32, 32, 9) INST_WGRAD(32, 32, 1)
+#define INST_WGRAD_SW(CI, CO) template __global__ void conv_wgrad_kernel<CI, CO, 9, 1>(const WgradParams); \
+                              template __global__ void conv_wgrad_kernel<CI, CO, 9, 2>(const WgradParams);
+INST_WGRAD_SW(64, 64) INST_WGRAD_SW(32, 64) INST_WGRAD_SW(64, 32) INST_WGRAD_SW(32, 32)
 
 // dst[co*s_co + ci*s_ci + t*s_t] (+)= sum_slices slab[slice][t][ci][co]; the trailing rows are the fused bias gradient
 // db[co] (+)= sum_slices bias_slab[slice][co].  Each thread owns 4 consecutive co (one 16-byte load per slice);
@@ -676,7 +712,7 @@ int ssie_launch_fprop(const ConvParams& p, hipStream_t st)
     return na <= 3 ? launch_fprop_t<1, 3, 8>(p, lds, st) : (na <= 6 ? launch_fprop_t<1, 6, 8>(p, lds, st) : launch_fprop_t<1, 9, 8>(p, lds, st));
 }
 
-template <int CI, int CO, int NU>
+template <int CI, int CO, int NU, int SW = 0>
 static int launch_wgrad_t(const WgradParams& p, hipStream_t st)
 {
     size_t lds = ((size_t)p.hp_h * p.hp_w * CI + (size_t)p.th * SSIE_TW * CO) * 4;
@@ -687,10 +723,26 @@ static int launch_wgrad_t(const WgradParams& p, hipStream_t st)
     }
     if (lds > 160 * 1024) return 23;
     static bool set = false;
-    if (!set) { hipFuncSetAttribute((const void*)conv_wgrad_kernel<CI, CO, NU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    if (!set) { hipFuncSetAttribute((const void*)conv_wgrad_kernel<CI, CO, NU, SW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
     dim3 grid(p.nslices, p.ci_blocks * p.co_blocks, p.tap_groups);
-    hipLaunchKernelGGL((conv_wgrad_kernel<CI, CO, NU>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv_wgrad_kernel<CI, CO, NU, SW>), grid, dim3(256), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : 24;
+}
+
+int ssie_wgrad_sliding = 1;      // A/B switch: 1 = sliding-window K loop for stride-1 3x3 / 9x9 layers
+extern "C" void ssie_debug_set_wgrad_sliding(int v) { ssie_wgrad_sliding = v; }
+
+// 1: the tap list is a 3 x 3 block, 2: rows of a 9 x 9 kernel (each group of 9 = one row, dx ascending), 0: anything else
+static int wgrad_window_kind(const WgradParams& p)
+{
+    if (!ssie_wgrad_sliding || p.si != 1 || p.th != 8 || (p.ntaps != 9 && p.ntaps != 81)) return 0;
+    const int ndx = p.ntaps == 9 ? 3 : 9;
+    for (int t = 0; t < p.ntaps; ++t) {
+        const int g = t / 9, u = t % 9;
+        const int dy0 = p.tap_dy[g * 9], dx0 = p.min_dx;
+        if (p.tap_dy[t] != dy0 + u / ndx || p.tap_dx[t] != dx0 + u % ndx) return 0;
+    }
+    return p.ntaps == 9 ? 1 : 2;
 }
 
 // cib/cob chosen by the caller through ci_pad/ci_blocks (ci_pad = ci_blocks*CIB)
@@ -698,6 +750,19 @@ int ssie_launch_wgrad(const WgradParams& p, hipStream_t st)
 {
     const int cib = p.ci_pad / p.ci_blocks, cob = p.co_pad / p.co_blocks;
     const bool one = p.ntaps == 1;
+    const int sw = wgrad_window_kind(p);
+    if (sw == 1) {
+        if (cib == 64 && cob == 64) return launch_wgrad_t<64, 64, 9, 1>(p, st);
+        if (cib == 32 && cob == 64) return launch_wgrad_t<32, 64, 9, 1>(p, st);
+        if (cib == 64 && cob == 32) return launch_wgrad_t<64, 32, 9, 1>(p, st);
+        if (cib == 32 && cob == 32) return launch_wgrad_t<32, 32, 9, 1>(p, st);
+    }
+    if (sw == 2) {
+        if (cib == 64 && cob == 64) return launch_wgrad_t<64, 64, 9, 2>(p, st);
+        if (cib == 32 && cob == 64) return launch_wgrad_t<32, 64, 9, 2>(p, st);
+        if (cib == 64 && cob == 32) return launch_wgrad_t<64, 32, 9, 2>(p, st);
+        if (cib == 32 && cob == 32) return launch_wgrad_t<32, 32, 9, 2>(p, st);
+    }
     if (cib == 64 && cob == 64) return one ? launch_wgrad_t<64, 64, 1>(p, st) : launch_wgrad_t<64, 64, 9>(p, st);
     if (cib == 32 && cob == 64) return one ? launch_wgrad_t<32, 64, 1>(p, st) : launch_wgrad_t<32, 64, 9>(p, st);
     if (cib == 64 && cob == 32) return one ? launch_wgrad_t<64, 32, 1>(p, st) : launch_wgrad_t<64, 32, 9>(p, st);

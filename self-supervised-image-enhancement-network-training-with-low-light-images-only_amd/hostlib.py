@@ -48,6 +48,8 @@ def lib():
         L.ssie_debug_set_overlap(int(os.environ["SSIE_OVERLAP"]))
     if os.environ.get("SSIE_MIN_TILES16") is not None:  # dev switch: threshold below which 8 x 16 tiles replace 16 x 16
         L.ssie_debug_set_fprop_min_tiles16(int(os.environ["SSIE_MIN_TILES16"]))
+    if os.environ.get("SSIE_WGRAD_SLIDING") is not None:  # dev switch: 0 = generic wgrad K loop everywhere
+        L.ssie_debug_set_wgrad_sliding(int(os.environ["SSIE_WGRAD_SLIDING"]))
     if os.environ.get("SSIE_WIDE") is not None:         # dev switch: 0 = no 16 x 32 tiles
         L.ssie_debug_set_fprop_wide(int(os.environ["SSIE_WIDE"]))
     if os.environ.get("SSIE_V2_SPLIT") is not None:     # dev switch: 0 = never split a CU between two 4-wave workgroups
