@@ -259,6 +259,11 @@ __global__ __launch_bounds__(256, ((NA <= 3 && TH == 8) ? 3 : 2)) void conv_fpro
 INST_FPROP(1, 3, 8) INST_FPROP(1, 6, 8) INST_FPROP(1, 9, 8) INST_FPROP(2, 3, 8) INST_FPROP(2, 6, 8) INST_FPROP(2, 9, 8)
 INST_FPROP(1, 6, 16) INST_FPROP(2, 6, 16)
 
+__device__ f32x4 ssie_zero_page_w[4];     // zero-initialised: source of the padding slots of the wgrad DMA staging
+#define GLDS16W(gptr, lptr)                                                                            \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),            \
+                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
 // ---------------------------------------------------------------------------------------------
 // wgrad: dW[tap][ci][co] = sum_positions X[pos*si + tap][ci] * G[pos][co]
 // GEMM view: M = ci (A operand), N = co (B operand), K = positions (2 per MFMA).
@@ -326,6 +331,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     const int bcol = tid % COB, brow = tid / COB;
     float bsum = 0.f;
 
+    // tile-invariant part of the halo staging: (row, column, channel quad) of this thread's LDS slots
+    constexpr int MAXX = (CIB == 64) ? 12 : 6;           // ceil(max halo pixels of a sliding-window group (10 x 18 or 8 x 24) * CI4 / 256)
+    constexpr int PT_MAX = 8 * SSIE_TW;
+    const int nxs = HP * CI4;
+    const bool up = s.sy != 1.f || s.sx != 1.f;
+    int xd[MAXX];
+    if constexpr (SW != 0) {
+#pragma unroll
+        for (int it = 0; it < MAXX; ++it) {
+            const int id = min(it * 256 + tid, nxs - 1);
+            const int pix = id / CI4, hy = pix / p.hp_w;
+            xd[it] = (hy << 12) | ((pix - hy * p.hp_w) << 4) | (id % CI4);
+        }
+    }
+
 #ifdef SSIE_STAMP
     unsigned long long ws_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ws_t_ = __builtin_amdgcn_s_memtime(); ws_[0] = ws_t_; ws_[4] = __builtin_amdgcn_s_memrealtime();
 #define WST(k) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); ws_[k] += t_ - ws_t_; ws_t_ = t_; } while (0)
@@ -341,6 +361,43 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         const int vy0 = a0 * p.si + gmin_dy, vx0 = b0 * p.si + p.min_dx;
         __syncthreads();
         WST(2);
+        if constexpr (SW != 0) {
+        // staging by global->LDS DMA (16 bytes per lane, LDS written linearly: slot id = it*256 + tid): no staging VGPRs,
+        // no ds_write pass and ~10x fewer instructions than the register path - the staging wave shares its SIMD with the
+        // other workgroup's MFMA stream and was starved of issue slots (43 % of a wave's time, tools/stamp_wgrad.py).
+        // Out-of-image / out-of-channel slots read a zero page; padding channels inside a valid quad are whatever the
+        // tensor holds there - they only reach output columns >= Cout, which the slab reduction never reads.
+#pragma unroll
+        for (int it = 0; it < MAXX; ++it) {
+            if (it * 256 >= nxs) break;                                   // wave-uniform
+            const int id = it * 256 + tid;
+            const int hy = xd[it] >> 12, hx = (xd[it] >> 4) & 255, j = xd[it] & 15;
+            const int vy = vy0 + hy, vx = vx0 + hx, c = ci0 + 4 * j;
+            const bool ok = (unsigned)vy < (unsigned)p.Hv && (unsigned)vx < (unsigned)p.Wv && c < s.C;
+            int y = vy, x = vx;
+            if (up) {
+                const int cy = min(max(vy, 0), p.Hv - 1), cx = min(max(vx, 0), p.Wv - 1);
+                y = min((int)floorf((float)cy * s.sy), s.Hs - 1);
+                x = min((int)floorf((float)cx * s.sx), s.Ws - 1);
+            }
+            const unsigned off = (unsigned)((n * s.Hs + y) * s.Ws + x) * (unsigned)s.cstride + (unsigned)(s.coff + c);
+            const f32x4* gp = ok ? (const f32x4*)(s.ptr + off) : (const f32x4*)ssie_zero_page_w;
+            if (id < nxs) GLDS16W(gp, (f32x4*)Xs + it * 256 + wave * 64);
+        }
+#pragma unroll
+        for (int it = 0; it < PT_MAX * CO4 / 256; ++it) {
+            if (it * 256 >= PT * CO4) break;
+            const int id = it * 256 + tid;
+            const int pix = id / CO4, j = id % CO4;
+            const int a = a0 + pix / SSIE_TW, b = b0 + pix % SSIE_TW, c = co0 + 4 * j;
+            const bool ok = a < p.Ho && b < p.Wo && c < ((p.Cout + 3) & ~3);
+            const unsigned off = (unsigned)((n * p.Ho + a) * p.Wo + b) * (unsigned)p.g_cstride + (unsigned)(p.g_coff + c);
+            const f32x4* gp = ok ? (const f32x4*)(p.g + off) : (const f32x4*)ssie_zero_page_w;
+            GLDS16W(gp, (f32x4*)Gs + it * 256 + wave * 64);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+        // generic layers (stride 2, 1 x 1, parity classes): register staging (measured faster there than the DMA path)
         // staging in batches of UB independent 16-byte loads per thread so the global latency is paid once per
         // batch, not once per element
         constexpr int UB = 6;
@@ -383,6 +440,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
                 const int id = base + u * 256 + tid;
                 if (id < PT * CO4) *(f32x4*)(Gs + (id / CO4) * COB + 4 * (id % CO4)) = r[u];
             }
+        }
         }
         WST(1);
         __syncthreads();
