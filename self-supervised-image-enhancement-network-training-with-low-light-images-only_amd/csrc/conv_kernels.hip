@@ -332,7 +332,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     float bsum = 0.f;
 
     // tile-invariant part of the halo staging: (row, column, channel quad) of this thread's LDS slots
-    constexpr int MAXX = (CIB == 64) ? 12 : 6;           // ceil(max halo pixels of a sliding-window group (10 x 18 or 8 x 24) * CI4 / 256)
+    // ceil(max halo pixels of a sliding-window group * CI4 / 256): 10 x 18 or 8 x 24 at stride 1, 9 x 33 at stride 2
+    constexpr int MAXX = (SW == 3 ? 19 : 12) * CIB / 64 + (SW == 3 && CIB == 32 ? 1 : 0);
     constexpr int PT_MAX = 8 * SSIE_TW;
     const int nxs = HP * CI4;
     const bool up = s.sy != 1.f || s.sx != 1.f;
@@ -451,27 +452,33 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         // (a register-ping-pong software pipeline of this loop cuts its cycles by 30 % in isolation but the clock and the
         //  co-resident workgroup's staging give all of it back: slower by 2-4 % in wall time, tools/stamp_wgrad.py)
         if constexpr (SW != 0) {
-            constexpr int NDY = SW == 1 ? 3 : 1, NDX = SW == 1 ? 3 : 9;
+            // SW = 1: 3 x 3 stride 1, 2: one row of a 9 x 9 (stride 1), 3: 3 x 3 stride 2 (two new halo columns per step)
+            constexpr int NDY = SW == 2 ? 1 : 3, NDX = SW == 2 ? 9 : 3, SI = SW == 3 ? 2 : 1;
             static_assert(NU == 9, "sliding-window loop: groups of 9 taps");
             for (int rp = wsub; rp < p.th / 2; rp += WSPLIT) {
                 const int row = 2 * rp + h;
-                const float* xr = Xs + row * p.hp_w * CIB + mi * 32 + li;       // halo (row + d, column c) = xr[(d*hp_w + c)*CIB]
+                const float* xr = Xs + row * SI * p.hp_w * CIB + mi * 32 + li; // halo (row*SI + d, column c) = xr[(d*hp_w + c)*CIB]
                 const float* gr = Gs + row * SSIE_TW * COB + ni * 32 + li;
                 const int rstr = p.hp_w * CIB;
                 float win[NDY][NDX];                                            // win[d][c % NDX] = halo column c of tap row d
 #pragma unroll
                 for (int d = 0; d < NDY; ++d)
 #pragma unroll
-                    for (int c = 0; c < NDX - 1; ++c) win[d][c] = xr[d * rstr + c * CIB];
+                    for (int c = 0; c < NDX - SI; ++c) win[d][c] = xr[d * rstr + c * CIB];
 #pragma unroll
                 for (int x = 0; x < SSIE_TW; ++x) {
 #pragma unroll
-                    for (int d = 0; d < NDY; ++d) win[d][(x + NDX - 1) % NDX] = xr[d * rstr + (x + NDX - 1) * CIB];
+                    for (int d = 0; d < NDY; ++d)
+#pragma unroll
+                        for (int e = 0; e < SI; ++e) {
+                            const int c = x * SI + NDX - SI + e;                // the SI new halo columns of this step
+                            win[d][c % NDX] = xr[d * rstr + c * CIB];
+                        }
                     const float b = gr[x * COB];
 #pragma unroll
                     for (int d = 0; d < NDY; ++d)
 #pragma unroll
-                        for (int c = 0; c < NDX; ++c) acc[d * NDX + c] = MFMA32(win[d][(x + c) % NDX], b, acc[d * NDX + c]);
+                        for (int c = 0; c < NDX; ++c) acc[d * NDX + c] = MFMA32(win[d][(x * SI + c) % NDX], b, acc[d * NDX + c]);
                 }
             }
         } else {
@@ -554,6 +561,7 @@ INST_WGRAD(32, 32, 9) INST_WGRAD(32, 32, 1)
 #define INST_WGRAD_SW(CI, CO) template __global__ void conv_wgrad_kernel<CI, CO, 9, 1>(const WgradParams); \
                               template __global__ void conv_wgrad_kernel<CI, CO, 9, 2>(const WgradParams);
 INST_WGRAD_SW(64, 64) INST_WGRAD_SW(32, 64) INST_WGRAD_SW(64, 32) INST_WGRAD_SW(32, 32)
+template __global__ void conv_wgrad_kernel<64, 64, 9, 3>(const WgradParams);
 
 // dst[co*s_co + ci*s_ci + t*s_t] (+)= sum_slices slab[slice][t][ci][co]; the trailing rows are the fused bias gradient
 // db[co] (+)= sum_slices bias_slab[slice][co].  Each thread owns 4 consecutive co (one 16-byte load per slice);
@@ -793,14 +801,15 @@ extern "C" void ssie_debug_set_wgrad_sliding(int v) { ssie_wgrad_sliding = v; }
 // 1: the tap list is a 3 x 3 block, 2: rows of a 9 x 9 kernel (each group of 9 = one row, dx ascending), 0: anything else
 static int wgrad_window_kind(const WgradParams& p)
 {
-    if (!ssie_wgrad_sliding || p.si != 1 || p.th != 8 || (p.ntaps != 9 && p.ntaps != 81)) return 0;
+    if (!ssie_wgrad_sliding || (p.ntaps != 9 && p.ntaps != 81)) return 0;
+    if (!((p.si == 1 && p.th == 8) || (p.si == 2 && p.th == 4 && p.ntaps == 9))) return 0;
     const int ndx = p.ntaps == 9 ? 3 : 9;
     for (int t = 0; t < p.ntaps; ++t) {
         const int g = t / 9, u = t % 9;
         const int dy0 = p.tap_dy[g * 9], dx0 = p.min_dx;
         if (p.tap_dy[t] != dy0 + u / ndx || p.tap_dx[t] != dx0 + u % ndx) return 0;
     }
-    return p.ntaps == 9 ? 1 : 2;
+    return p.ntaps == 9 ? (p.si == 2 ? 3 : 1) : 2;
 }
 
 // cib/cob chosen by the caller through ci_pad/ci_blocks (ci_pad = ci_blocks*CIB)
@@ -815,6 +824,7 @@ int ssie_launch_wgrad(const WgradParams& p, hipStream_t st)
         if (cib == 64 && cob == 32) return launch_wgrad_t<64, 32, 9, 1>(p, st);
         if (cib == 32 && cob == 32) return launch_wgrad_t<32, 32, 9, 1>(p, st);
     }
+    if (sw == 3 && cib == 64 && cob == 64) return launch_wgrad_t<64, 64, 9, 3>(p, st);
     if (sw == 2) {
         if (cib == 64 && cob == 64) return launch_wgrad_t<64, 64, 9, 2>(p, st);
         if (cib == 32 && cob == 64) return launch_wgrad_t<32, 64, 9, 2>(p, st);
