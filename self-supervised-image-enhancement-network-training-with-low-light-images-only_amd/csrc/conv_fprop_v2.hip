@@ -54,14 +54,16 @@ __device__ __forceinline__ const f32x4* ssie_virtual_addr(const SrcSel& s, bool 
 // 256-thread workgroups per CU, 32-channel tiles, ~78 KiB LDS each): the two workgroups drift out of phase, so the DMA
 // issue / epilogue / barrier phases of one run underneath the MFMA phase of the other (tools/stamp_v2.py: those phases
 // are ~20 % of a lock-stepped 8-wave workgroup's time)
-template <int NT, int NA2, int NW>
+// TH = 16: stride-1 layers; TH = 8: stride-2 layers (8 x 16 output positions read a 17 x 33 halo)
+template <int NT, int NA2, int NW, int TH>
 __global__ __launch_bounds__(64 * NW, 2) void conv_fprop_v2_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    constexpr int BN = 32 * NT, TH = 16;
+    constexpr int BN = 32 * NT;
     constexpr int NTHR = 64 * NW;
-    constexpr int WM = (NT == 2) ? NW / 2 : NW;     // waves along M; the 16 x 16 tile has 8 M-tiles of 2 x 16 positions
-    constexpr int MT = 8 / WM;
+    constexpr int WM = (NT == 2) ? NW / 2 : NW;     // waves along M; a TH x 16 tile has TH/2 M-tiles of 2 x 16 positions
+    constexpr int MT = (TH / 2) / WM;
+    static_assert(MT >= 1, "tile too small for the wave grid");
     constexpr int BSZ = SSIE_TG * 4 * BN;           // float4 per B buffer
     const int HP = p.hp_h * p.hp_w, HP4 = HP * 4;
     f32x4* As0 = (f32x4*)smem_f;                    // [2][HP4]
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fprop_v2_kernel(const ConvPar
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int mt = wm * MT + m;
-        pixbase[m] = (2 * mt + (li >> 4)) * p.hp_w + (li & 15);
+        pixbase[m] = (2 * mt + (li >> 4)) * p.si * p.hp_w + (li & 15) * p.si;
     }
     const int ngroups = (p.ntaps + SSIE_TG - 1) / SSIE_TG;
     const int nsteps = p.nchunks * ngroups;
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fprop_v2_kernel(const ConvPar
         if ((G) == 0) {                                                                                       \
             const SrcSel s_ = ssie_pick_src(p, (CHUNK) * SSIE_CK);                                            \
             const bool up_ = s_.sy != 1.f || s_.sx != 1.f;                                                    \
-            const int vy0_ = (A0_) + p.min_dy, vx0_ = (B0_) + p.min_dx;                                       \
+            const int vy0_ = (A0_) * p.si + p.min_dy, vx0_ = (B0_) * p.si + p.min_dx;                                       \
             f32x4* abuf_ = As0 + (ABUF) * HP4;                                                                \
             _Pragma("unroll") for (int i_ = 0; i_ < NA2; ++i_) {                                              \
                 if (tid + i_ * NTHR < HP4) {                                                                  \
@@ -474,8 +476,8 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_v2w_kernel(const ConvParams
 }
 
 
-#define INST_V2(NT, NA2, NW) template __global__ void conv_fprop_v2_kernel<NT, NA2, NW>(const ConvParams);
-INST_V2(1, 3, 8) INST_V2(1, 5, 8) INST_V2(2, 3, 8) INST_V2(2, 5, 8) INST_V2(1, 6, 4)
+#define INST_V2(NT, NA2, NW, TH) template __global__ void conv_fprop_v2_kernel<NT, NA2, NW, TH>(const ConvParams);
+INST_V2(1, 3, 8, 16) INST_V2(1, 5, 8, 16) INST_V2(2, 3, 8, 16) INST_V2(2, 5, 8, 16) INST_V2(1, 6, 4, 16) INST_V2(2, 5, 8, 8)
 template __global__ void conv_fprop_v2w_kernel<5>(const ConvParams);
 
 size_t ssie_fprop_v2_lds_bytes(const ConvParams& p, int nt)
@@ -483,11 +485,16 @@ size_t ssie_fprop_v2_lds_bytes(const ConvParams& p, int nt)
     return 2 * ((size_t)p.hp_h * p.hp_w * 64 + (size_t)SSIE_TG * 4 * 32 * nt * 16) + (size_t)SSIE_MAX_TAPS * 4 + 16;
 }
 
-// eligible: stride-1 geometry built with th == 16 whose double-buffered tiles fit the 160 KiB LDS
+int ssie_fprop_v2_stride2 = 1;     // A/B switch: 1 = stride-2 64-channel layers on the DMA kernel (8 x 16 tiles)
+extern "C" void ssie_debug_set_fprop_v2_stride2(int v) { ssie_fprop_v2_stride2 = v; }
+
+// eligible: stride-1 geometry built with th == 16 (or stride-2, th == 8, 64-channel tiles, enough tiles to fill the chip)
+// whose double-buffered tiles fit the 160 KiB LDS
 bool ssie_fprop_v2_ok(const ConvParams& p)
 {
-    if (p.th != 16 || p.si != 1) return false;
     const int nt = (p.Cout_pad % 64 == 0) ? 2 : 1;
+    if (!((p.th == 16 && p.si == 1) || (p.th == 8 && p.si == 2 && nt == 2 && ssie_fprop_v2_stride2 &&
+           (long)p.N * p.tiles_y * p.tiles_x * p.co_blocks >= ssie_fprop_min_tiles16))) return false;
     const int na2 = (p.hp_h * p.hp_w * 4 + 511) / 512;
     return na2 <= 5 && ssie_fprop_v2_lds_bytes(p, nt) <= 160 * 1024;
 }
@@ -497,15 +504,15 @@ static int g_v2_split_min_tiles = 1024;   // ... for launches with at least this
 extern "C" void ssie_debug_set_fprop_v2_split(int on) { g_v2_split = on; }
 extern "C" void ssie_debug_set_fprop_v2_split_min_tiles(int v) { g_v2_split_min_tiles = v; }
 
-template <int NT, int NA2, int NW>
+template <int NT, int NA2, int NW, int TH = 16>
 static int launch_v2_t(const ConvParams& p, size_t lds, hipStream_t st)
 {
     static bool set = false;
-    if (!set) { hipFuncSetAttribute((const void*)conv_fprop_v2_kernel<NT, NA2, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    if (!set) { hipFuncSetAttribute((const void*)conv_fprop_v2_kernel<NT, NA2, NW, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
     const size_t tiles = (size_t)p.N * p.tiles_y * p.tiles_x * p.co_blocks;
     const size_t cap = NW == 8 ? 256 : 512;
     const size_t wgs = tiles < cap ? tiles : cap;
-    hipLaunchKernelGGL((conv_fprop_v2_kernel<NT, NA2, NW>), dim3((unsigned)wgs), dim3(64 * NW), lds, st, p);
+    hipLaunchKernelGGL((conv_fprop_v2_kernel<NT, NA2, NW, TH>), dim3((unsigned)wgs), dim3(64 * NW), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : 18;
 }
 
@@ -535,6 +542,7 @@ int ssie_launch_fprop_v2(const ConvParams& p, hipStream_t st)
     }
     const int na2 = (p.hp_h * p.hp_w * 4 + 511) / 512;
     const size_t lds = ssie_fprop_v2_lds_bytes(p, nt);
+    if (p.th == 8) return launch_v2_t<2, 5, 8, 8>(p, lds, st);
     if (nt == 2) return na2 <= 3 ? launch_v2_t<2, 3, 8>(p, lds, st) : launch_v2_t<2, 5, 8>(p, lds, st);
     return na2 <= 3 ? launch_v2_t<1, 3, 8>(p, lds, st) : launch_v2_t<1, 5, 8>(p, lds, st);
 }

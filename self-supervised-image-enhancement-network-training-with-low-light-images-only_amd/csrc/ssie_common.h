@@ -98,6 +98,7 @@ int ssie_launch_fprop(const ConvParams& p, hipStream_t st);
 bool ssie_fprop_v2_ok(const ConvParams& p);            // conv_fprop_v2.hip
 int ssie_launch_fprop_v2(const ConvParams& p, hipStream_t st);
 int ssie_launch_fprop_bf16(const ConvParams& p, hipStream_t st);   // conv_fprop_bf16.hip; p from ssie_make_conv_bf16
+extern int ssie_fprop_min_tiles16;                     // launches with fewer tiles than this use the 8 x 16 register-staged kernel (layer_ops.hip)
 extern int ssie_fprop_use_v2;                          // tuning / A-B switch (1 = use the 512-thread DMA kernel when eligible)
 int ssie_launch_wgrad(const WgradParams& p, hipStream_t st);
 int ssie_launch_wgrad_reduce(const float* slabs, int nslices, int ntaps, int ci_pad, int co_pad, int Cin, int Cout,

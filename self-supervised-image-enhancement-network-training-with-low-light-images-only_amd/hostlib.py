@@ -50,6 +50,8 @@ def lib():
         L.ssie_debug_set_fprop_min_tiles16(int(os.environ["SSIE_MIN_TILES16"]))
     if os.environ.get("SSIE_WGRAD_SLIDING") is not None:  # dev switch: 0 = generic wgrad K loop everywhere
         L.ssie_debug_set_wgrad_sliding(int(os.environ["SSIE_WGRAD_SLIDING"]))
+    if os.environ.get("SSIE_V2_STRIDE2") is not None:   # dev switch: 0 = stride-2 layers on the register-staged kernel
+        L.ssie_debug_set_fprop_v2_stride2(int(os.environ["SSIE_V2_STRIDE2"]))
     if os.environ.get("SSIE_WIDE") is not None:         # dev switch: 0 = no 16 x 32 tiles
         L.ssie_debug_set_fprop_wide(int(os.environ["SSIE_WIDE"]))
     if os.environ.get("SSIE_V2_SPLIT") is not None:     # dev switch: 0 = never split a CU between two 4-wave workgroups
