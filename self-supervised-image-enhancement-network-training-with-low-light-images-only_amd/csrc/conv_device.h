@@ -35,6 +35,16 @@ __device__ __forceinline__ SrcSel ssie_pick_src(const PT& p, int c_first)
     return r;
 }
 
+// single-source layers: the descriptor of source 0
+template <typename PT>
+__device__ __forceinline__ SrcSel ssie_only_src(const PT& p)
+{
+    SrcSel r;
+    r.ptr = p.src[0].ptr; r.C = p.src[0].C; r.cstride = p.src[0].cstride; r.coff = p.src[0].coff;
+    r.Hs = p.src[0].Hs; r.Ws = p.src[0].Ws; r.sy = p.src[0].sy; r.sx = p.src[0].sx; r.cbeg = 0;
+    return r;
+}
+
 // load 4 consecutive channels of virtual pixel (n, vy, vx); zero outside the image / channel range.
 // Branch-free: the address is clamped into the tensor and the value is zeroed afterwards, so a batch of these
 // compiles to back-to-back global_load_dwordx4 without exec-mask regions (hipcc serialises predicated loads

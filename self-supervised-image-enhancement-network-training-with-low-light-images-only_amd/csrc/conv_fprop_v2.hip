@@ -277,7 +277,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fprop_v2_kernel(const ConvPar
 // costs 4 ds_read_b128 per 16 MFMAs instead of 3 per 8, and a step moves 76 KB of DMA for twice the FLOPs of the
 // 16 x 16 tile's 57.6 KB: -33 % LDS bytes, -34 % DMA bytes, half the barriers per FLOP (the fp32 MFMA kernels are
 // clock-limited by energy per FLOP).
-template <int NA2>
+// SINGLE = the virtual input is one tensor (no concat): the source descriptor is then a compile-time choice and the two
+// unused descriptors never occupy scalar registers (the kernel spills ~130 SGPRs to VGPR lanes otherwise, and every
+// restore is a v_readlane + wait states inside the per-step DMA-issue phase).
+template <int NA2, bool SINGLE>
 __global__ __launch_bounds__(512, 2) void conv_fprop_v2w_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_v2w_kernel(const ConvParams
 #define V2_PREFETCH(CHUNK, G, N_, A0_, B0_, CO0_, BUF, ABUF)                                                        \
     {                                                                                                         \
         if ((G) == 0) {                                                                                       \
-            const SrcSel s_ = ssie_pick_src(p, (CHUNK) * SSIE_CK);                                            \
+            const SrcSel s_ = SINGLE ? ssie_only_src(p) : ssie_pick_src(p, (CHUNK) * SSIE_CK);                \
             const bool up_ = s_.sy != 1.f || s_.sx != 1.f;                                                    \
             const int vy0_ = (A0_) + p.min_dy, vx0_ = (B0_) + p.min_dx;                                       \
             f32x4* abuf_ = As0 + (ABUF) * HP4;                                                                \
@@ -478,7 +481,8 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_v2w_kernel(const ConvParams
 
 #define INST_V2(NT, NA2, NW, TH) template __global__ void conv_fprop_v2_kernel<NT, NA2, NW, TH>(const ConvParams);
 INST_V2(1, 3, 8, 16) INST_V2(1, 5, 8, 16) INST_V2(2, 3, 8, 16) INST_V2(2, 5, 8, 16) INST_V2(1, 6, 4, 16) INST_V2(2, 5, 8, 8)
-template __global__ void conv_fprop_v2w_kernel<5>(const ConvParams);
+template __global__ void conv_fprop_v2w_kernel<5, false>(const ConvParams);
+template __global__ void conv_fprop_v2w_kernel<5, true>(const ConvParams);
 
 size_t ssie_fprop_v2_lds_bytes(const ConvParams& p, int nt)
 {
@@ -522,9 +526,15 @@ int ssie_launch_fprop_v2(const ConvParams& p, hipStream_t st)
     if (p.tw == 32) {      // geometry built for the wide kernel (ssie_make_conv)
         const size_t lds = ssie_fprop_v2_lds_bytes(p, 2);
         static bool set = false;
-        if (!set) { hipFuncSetAttribute((const void*)conv_fprop_v2w_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+        if (!set) {
+            hipFuncSetAttribute((const void*)conv_fprop_v2w_kernel<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute((const void*)conv_fprop_v2w_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            set = true;
+        }
         const size_t tiles = (size_t)p.N * p.tiles_y * p.tiles_x * p.co_blocks;
-        hipLaunchKernelGGL((conv_fprop_v2w_kernel<5>), dim3((unsigned)(tiles < 256 ? tiles : 256)), dim3(512), lds, st, p);
+        const dim3 grid((unsigned)(tiles < 256 ? tiles : 256));
+        if (p.nsrc == 1) hipLaunchKernelGGL((conv_fprop_v2w_kernel<5, true>), grid, dim3(512), lds, st, p);
+        else hipLaunchKernelGGL((conv_fprop_v2w_kernel<5, false>), grid, dim3(512), lds, st, p);
         return hipGetLastError() == hipSuccess ? 0 : 19;
     }
     // 32-channel layers: two 4-wave workgroups per CU (both must fit the LDS, and there must be enough tiles to fill
