@@ -148,6 +148,7 @@ class LowLightEnhance(nn.Module):
         self.freeze_decom_epochs = 0
         # opt-in (not a reference kwarg): forward() under torch.no_grad() uses bf16 storage + bf16 MFMA; outputs stay fp32
         self.bf16_inference = False
+        self.max_cached_plans = 4
         self.all_epoch_losses = {k: [] for k in LOSS_KEYS}
 
         self._table, total = H.param_table(input_channels)
@@ -223,13 +224,19 @@ class LowLightEnhance(nn.Module):
             raise H.SsieError("model parameters and input are on different devices")
         self._ensure_device_layout()
         key = (x.shape[0], x.shape[2], x.shape[3])
-        plan = self._plans.get(key)
+        plan = self._plans.pop(key, None)
         if plan is None:
+            # a plan owns its workspace (4 GiB for 32 training patches, 17 GiB for one 1024 x 1024 cube): evaluating many
+            # differently sized images must not keep them all, so only the most recently used few stay alive
+            while len(self._plans) >= self.max_cached_plans:
+                self._plans.pop(next(iter(self._plans)))
             plan = H.Plan(x.shape[0], self.input_channels, x.shape[2], x.shape[3], self.coefs(), self._flat, self._gflat)
             self._plans[key] = plan
             plan._coefs = tuple(self.coefs().values())
-        elif plan._coefs != tuple(self.coefs().values()):
-            plan.set_coefs(self.coefs()); plan._coefs = tuple(self.coefs().values())
+        else:
+            self._plans[key] = plan                       # re-insert: dict order = recency
+            if plan._coefs != tuple(self.coefs().values()):
+                plan.set_coefs(self.coefs()); plan._coefs = tuple(self.coefs().values())
         return plan
 
     @staticmethod
