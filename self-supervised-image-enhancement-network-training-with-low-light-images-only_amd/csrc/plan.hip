@@ -353,7 +353,7 @@ struct Builder {
         const float* sp = pl.buf(src); const float* yp = y ? pl.buf(y) : nullptr; float* dp = pl.buf(dst);
         const int ycs = y ? pl.bi(y).cs : 0, scs = sb.cs, dcs = db.cs;
         const long npix = (long)sb.N * sb.H * sb.W;
-        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_mask_axpy(sp, scs, yp, ycs, mode, dp, dcs, npix, C, accumulate, st); }));
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_mask_axpy(sp, scs, yp, ycs, mode, dp, dcs, npix, C, accumulate, st); }, K_ELEMENTWISE, 0.0, std::string("mask_axpy ") + src + "->" + dst));
     }
 
     void upadj(std::vector<Fn>& ops, const char* src, int Hv, int Wv, const char* dst, int accumulate)
@@ -362,7 +362,7 @@ struct Builder {
         const BufInfo& db = pl.bi(dst);
         const float* sp = pl.buf(src); float* dp = pl.buf(dst);
         const int scs = pl.bi(src).cs, dcs = db.cs, Hs = db.H, Ws = db.W, N = pl.N;
-        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_upsample_adjoint(sp, Hv, Wv, scs, dp, Hs, Ws, dcs, N, 64, accumulate, st); }));
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_upsample_adjoint(sp, Hv, Wv, scs, dp, Hs, Ws, dcs, N, 64, accumulate, st); }, K_ELEMENTWISE, 0.0, "upsample_adjoint"));
     }
 };
 
@@ -423,7 +423,7 @@ int build_illum_fwd(Builder& b, std::vector<Fn>& ops)
     if (!b.dry) {
         const float* RL = pl.buf("RL_1"); const float* D = pl.buf("D"); float* S = pl.buf("S");
         const int rl = pl.CRL, cx = pl.CX, B = pl.B; const long npix = (long)pl.N * H * W;
-        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_compose(RL, rl, D, 4, S, cx, npix, B, st); }));
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_compose(RL, rl, D, 4, S, cx, npix, B, st); }, K_ELEMENTWISE, 0.0, "compose"));
     }
     return 0;
 }
@@ -593,7 +593,7 @@ int build_all(Plan& pl, bool dry)
         const float* gS = pl.buf("gS"); const float* RL = pl.buf("RL_1"); float* gRL = pl.buf("gRL");
         const float* D = pl.buf("D"); float* gD = pl.buf("gD");
         const int cx = pl.CX, rl = pl.CRL, B = pl.B; const long npix = (long)pl.N * pl.H * pl.W;
-        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_product_node(gS, cx, RL, gRL, rl, D, gD, 4, npix, B, st); }));
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_product_node(gS, cx, RL, gRL, rl, D, gD, 4, npix, B, st); }, K_ELEMENTWISE, 0.0, "product_node"));
     }
     CK(build_illum_bwd(b, ops));
     b.mask_axpy(ops, "gRL", "RL_1", MASK_SIGMOID, "G8", pl.B + 1, 0);
