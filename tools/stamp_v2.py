@@ -15,15 +15,17 @@ def main():
     L = C.CDLL(out)
     L.ssie_op_workspace_bytes.restype = C.c_size_t
     dev = "cuda"
-    x = torch.randn(N, hw, hw, cin, device=dev); w = torch.randn(cout, cin, k, k, device=dev) * 0.05; b = torch.randn(cout, device=dev)
+    cs = (cin + 3) // 4 * 4
+    x = torch.randn(N, hw, hw, cs, device=dev); x[..., cin:] = 0; w = torch.randn(cout, cin, k, k, device=dev) * 0.05; b = torch.randn(cout, device=dev)
     o = torch.zeros(N, hw, hw, cout, device=dev)
     ws = torch.zeros(L.ssie_op_workspace_bytes(cin, cout, k) // 4 + 1, device=dev)
     nwg = 256
     stamps = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
-    arr = (H.SrcT * 1)(H.src_of(x, cin))
+    arr = (H.SrcT * 1)(H.src_of(x, cs))
     def run():
         return L.ssie_conv2d_fwd(arr, 1, N, hw, hw, H.ptr(w), cin, H.ptr(b), cout, k, 1, 1, None, None, H.ptr(o), cout, 0,
                                  H.ptr(ws), C.c_size_t(ws.numel() * 4), None)
+    rc = run(); assert rc == 0, f"ssie_conv2d_fwd rc={rc}"
     for _ in range(20):
         assert run() == 0
     torch.cuda.synchronize()
