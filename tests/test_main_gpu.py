@@ -70,3 +70,33 @@ def test_train_and_test_entry(tmp_path, monkeypatch):
     scal = net.train_step(x.cuda()).cpu().double().numpy()
     ref = np.array([vals[k] for k in O.LOSS_KEYS])
     assert np.all(np.abs(scal - ref) <= 2e-5 * np.abs(ref) + 1e-9), (scal, ref)
+
+
+def test_test_entry_bf16_inference_matches_fp32(tmp_path, monkeypatch):
+    """`--bf16_inference 1`: the test/eval forward runs the bf16 mixed-precision path; the written cubes must agree with the
+    fp32 run's to bf16 accuracy (PSNR >= 55 dB on the [0, 1]-normalised enhanced cube)."""
+    import scipy.io as sio
+    import ssie
+    ssie.load()
+    from ssie_amd import harness
+    spec = importlib.util.spec_from_file_location("ssie_main", os.path.join(ROOT, "main.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    os.makedirs(tmp_path / "test")
+    sio.savemat(str(tmp_path / "test" / "t.mat"), {"data": _cube(5, 72, 88)})
+    monkeypatch.chdir(tmp_path)
+    outs = {}
+    for flag in ("0", "1"):
+        argv = ["--config", os.path.join(ROOT, "config", "config_outdoor_jyu.yml"), "--channels", "31", "--model_name", "b" + flag,
+                "--test_data", str(tmp_path / "test"), "--bf16_inference", flag]
+        args = m.parse_args(argv)
+        torch.manual_seed(7)
+        net = m.build_model(args, torch.device("cuda"))
+        assert net.bf16_inference == (flag == "1")
+        cube = harness.load_hsi(str(tmp_path / "test" / "t.mat"), "data", "global_normalization", 4095.0, 238.0)
+        R, I, D, S = harness._enhance_whole(net, cube)              # what test_model runs per file (model.py:418-421)
+        outs[flag] = np.asarray(S, dtype=np.float64)
+    a, b = outs["0"], outs["1"]
+    assert a.shape == b.shape == (72, 88, 31)
+    mse = np.mean((a - b) ** 2)                 # cubes are normalised to [0, 1]
+    assert 10 * np.log10(1.0 / max(mse, 1e-30)) >= 55.0
+    assert not np.array_equal(a, b)            # the bf16 path really ran
