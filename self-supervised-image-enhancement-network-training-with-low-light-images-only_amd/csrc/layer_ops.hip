@@ -144,10 +144,14 @@ int ssie_make_conv_bf16(ConvParams& p, const SrcDesc* srcs, int nsrc, int N, int
     int mny, mxy, mnx, mxx; tap_extent(t, mny, mxy, mnx, mxx);
     p.nchunks = ssie_ceil_div(p.Cin, 32);
     p.th = si == 1 ? 16 : 8;
+    // 16 x 32 tiles (conv_fprop_bf16w_kernel) under the same conditions as the fp32 wide kernel
+    const int span = (mxy - mny) > (mxx - mnx) ? (mxy - mny) : (mxx - mnx);
+    p.tw = (ssie_fprop_wide && si == 1 && span <= 2 && p.Cout_pad % 64 == 0 && Wo >= 32 &&
+            (long)N * ssie_ceil_div(Ho, 16) * ssie_ceil_div(Wo, 32) * (p.Cout_pad / 64) >= ssie_fprop_wide_min_tiles) ? 32 : SSIE_TW;
     p.hp_h = (p.th - 1) * si + (mxy - mny) + 1;
-    p.hp_w = (SSIE_TW - 1) * si + (mxx - mnx) + 1;
+    p.hp_w = (p.tw - 1) * si + (mxx - mnx) + 1;
     p.tiles_y = ssie_ceil_div(Ho, p.th);
-    p.tw = SSIE_TW; p.tiles_x = ssie_ceil_div(Wo, SSIE_TW);
+    p.tiles_x = ssie_ceil_div(Wo, p.tw);
     p.out_bf16 = out_bf16;
     return 0;
 }

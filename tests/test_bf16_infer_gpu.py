@@ -31,8 +31,18 @@ def _plan(H, n, bands, h, w):
     return H.Plan(n, bands, h, w, O.JYU_COEFS, flat, torch.zeros_like(flat)), P
 
 
+@pytest.fixture(params=["heuristic", "tile16x32"])
+def wide_tiles(H, request):
+    """"tile16x32" forces conv_fprop_bf16w_kernel (the 16 x 32-tile kernel of the 1024 x 1024 layers) onto these small cubes"""
+    L = H.lib()
+    if request.param == "tile16x32":
+        L.ssie_debug_set_fprop_wide_min_tiles(1)
+    yield request.param
+    L.ssie_debug_set_fprop_wide_min_tiles(512)
+
+
 @pytest.mark.parametrize("n,bands,h,w", [(2, 31, 64, 64), (1, 31, 50, 38), (1, 31, 136, 200), (1, 7, 32, 32)])
-def test_bf16_enhance_vs_oracle(H, n, bands, h, w):
+def test_bf16_enhance_vs_oracle(H, n, bands, h, w, wide_tiles):
     plan, P = _plan(H, n, bands, h, w)
     x = O.synthetic_patches(n, bands, h, w)
     plan.enhance_fwd(x.cuda(), bf16=True)
