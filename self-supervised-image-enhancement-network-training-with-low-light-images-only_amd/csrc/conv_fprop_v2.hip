@@ -1,6 +1,7 @@
-// conv_fprop_v2_kernel: the stride-1 implicit-GEMM convolution (forward + data gradient) restructured for ONE
-// 512-thread workgroup per CU:
-//   * 16 x 16 output positions x 64 (or 32) channels per tile; 8 waves = 4 (M) x 2 (N), two waves per SIMD
+// conv_fprop_v2_kernel / conv_fprop_v2w_kernel: the implicit-GEMM convolution (forward + data gradient) of every launch
+// large enough to give each CU a tile, restructured for ONE 512-thread workgroup per CU:
+//   * 16 x 16 output positions (8 x 16 at stride 2) x 64 (or 32) channels per tile; 8 waves = 4 (M) x 2 (N), two waves per
+//     SIMD; the wide variant (big 64-channel 3x3 layers) takes 16 x 32 positions with a 64 x 64 register tile per wave
 //   * LDS is DOUBLE-buffered and filled by direct global->LDS DMA (global_load_lds_dwordx4): no staging VGPRs, no
 //     ds_write pass, and exactly ONE barrier per step - the loads of step s+1 are issued right after the barrier of
 //     step s and have the whole MFMA phase of step s to land
