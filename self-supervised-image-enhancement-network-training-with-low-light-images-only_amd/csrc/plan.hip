@@ -128,21 +128,24 @@ void build_buffers(Plan& pl)
 {
     const int N = pl.N, H = pl.H, W = pl.W, B = pl.B;
     const int H2 = pl.H2, W2 = pl.W2, H4 = pl.H4, W4 = pl.W4, H8 = pl.H8, W8 = pl.W8;
-    alloc(pl, "x", N, H, W, B); alloc(pl, "S", N, H, W, B); alloc(pl, "gS", N, H, W, B);
+    // Every tensor of the two decomposition passes is allocated as an adjacent [pass 1 ; pass 2] pair, i.e. ONE tensor of
+    // 2N patches: the weight gradients of both passes are then a single launch per layer over the doubled batch (half the
+    // wgrad launches and half the slab traffic of the shared decomposition weights).  x | S is such a pair too.
+    auto alloc2 = [&](const char* n1, const char* n2, int h, int w, int c) {
+        const size_t o1 = alloc(pl, n1, N, h, w, c);
+        pl.ws_floats = o1 + (size_t)N * h * w * ssie_round_up(c, 4);             // no alignment gap inside the pair
+        alloc(pl, n2, N, h, w, c);
+    };
+    alloc2("x", "S", H, W, B); alloc(pl, "gS", N, H, W, B);
     alloc(pl, "D", N, H, W, 1); alloc(pl, "gD", N, H, W, 1);
     alloc(pl, "gRL", N, H, W, B + 1);
-    for (int p = 1; p <= 2; ++p) {
-        auto nm = [&](const char* s) { return std::string(s) + (p == 1 ? "_1" : "_2"); };
-        alloc(pl, nm("c0").c_str(), N, H, W, 32); alloc(pl, nm("sh").c_str(), N, H, W, 64);
-        alloc(pl, nm("c1").c_str(), N, H, W, 64); alloc(pl, nm("c2").c_str(), N, H2, W2, 128);
-        alloc(pl, nm("c3").c_str(), N, H2, W2, 128); alloc(pl, nm("dc").c_str(), N, H, W, 64);
-        alloc(pl, nm("c5").c_str(), N, H, W, 64); alloc(pl, nm("c7").c_str(), N, H, W, 64);
-        alloc(pl, nm("RL").c_str(), N, H, W, B + 1);
-    }
-    // decomposition gradients (w.r.t. pre-activation), shared by both backward passes
-    alloc(pl, "G8", N, H, W, B + 1); alloc(pl, "G7", N, H, W, 64); alloc(pl, "G5", N, H, W, 64); alloc(pl, "G0", N, H, W, 32);
-    alloc(pl, "Gdc", N, H, W, 64); alloc(pl, "G3", N, H2, W2, 128); alloc(pl, "G2", N, H2, W2, 128);
-    alloc(pl, "G1", N, H, W, 64); alloc(pl, "Gsh", N, H, W, 64);
+    alloc2("c0_1", "c0_2", H, W, 32); alloc2("sh_1", "sh_2", H, W, 64); alloc2("c1_1", "c1_2", H, W, 64);
+    alloc2("c2_1", "c2_2", H2, W2, 128); alloc2("c3_1", "c3_2", H2, W2, 128); alloc2("dc_1", "dc_2", H, W, 64);
+    alloc2("c5_1", "c5_2", H, W, 64); alloc2("c7_1", "c7_2", H, W, 64); alloc2("RL_1", "RL_2", H, W, B + 1);
+    // decomposition gradients (w.r.t. pre-activation): pass 1 under the plain name, pass 2 as <name>_2 right behind it
+    alloc2("G8", "G8_2", H, W, B + 1); alloc2("G7", "G7_2", H, W, 64); alloc2("G5", "G5_2", H, W, 64); alloc2("G0", "G0_2", H, W, 32);
+    alloc2("Gdc", "Gdc_2", H, W, 64); alloc2("G3", "G3_2", H2, W2, 128); alloc2("G2", "G2_2", H2, W2, 128);
+    alloc2("G1", "G1_2", H, W, 64); alloc2("Gsh", "Gsh_2", H, W, 64);
     // illumination net
     alloc(pl, "a0", N, H, W, 64); alloc(pl, "a1", N, H2, W2, 64); alloc(pl, "a2", N, H4, W4, 64); alloc(pl, "a3", N, H8, W8, 64);
     alloc(pl, "qkv", N, H8, W8, 192); alloc(pl, "ao", N, H8, W8, 64); alloc(pl, "f1", N, H8, W8, 64); alloc(pl, "t3", N, H8, W8, 64);
@@ -306,8 +309,9 @@ struct Builder {
     }
 
     // weight gradient (+ fused bias gradient when with_bias) of a forward conv layer, one input source per call
+    // nbatch = 2: x and g name the pass-1 halves of [pass 1 ; pass 2] pairs and the launch covers both passes
     int wgrad(std::vector<Fn>& ops, const LayerP& L, int stride, SrcDesc x, int creal, int Hv, int Wv, int ci_off, const char* g,
-              int g_coff = 0, bool with_bias = false)
+              int g_coff = 0, bool with_bias = false, int nbatch = 1)
     {
         if (dry) return 0;
         const int T = L.k * L.k, pad = (L.k - 1) / 2;
@@ -318,7 +322,7 @@ struct Builder {
         WgradParams p;
         const int sl = pl.slab_seq++ & 1;
         const size_t soff = sl ? pl.slab_off2 : pl.slab_off;
-        int rc = ssie_make_wgrad(p, x, pl.N, Hv, Wv, 0, pl.buf(g), gb.cs, g_coff, L.cout, Ho, Wo, stride, t, pl.ws + soff, kWgs);
+        int rc = ssie_make_wgrad(p, x, pl.N * nbatch, Hv, Wv, 0, pl.buf(g), gb.cs, g_coff, L.cout, Ho, Wo, stride, t, pl.ws + soff, kWgs);
         if (rc) return rc;
         const size_t need = ssie_wgrad_slab_floats(p);
         if (need + (size_t)p.nslices * p.co_pad > pl.slab_cap) return SSIE_E_WORKSPACE;
@@ -329,7 +333,7 @@ struct Builder {
         float* bslab = with_bias ? pl.ws + soff + need : nullptr;
         float* db = with_bias ? pl.G + L.b : nullptr;
         p.bias_slabs = bslab;
-        const double fl = 2.0 * pl.N * Ho * Wo * (double)cout * creal * T;
+        const double fl = 2.0 * pl.N * nbatch * Ho * Wo * (double)cout * creal * T;
         char tag[96];
         snprintf(tag, sizeof(tag), "wgrad ci%d co%d taps%d si%d %dx%d slices%d", creal, cout, T, stride, Ho, Wo, p.nslices);
         ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_wgrad(p, st); }, K_WGRAD, fl, tag, sl));
@@ -337,12 +341,12 @@ struct Builder {
         return 0;
     }
 
-    void bias_grad(std::vector<Fn>& ops, const LayerP& L, const char* g, int g_coff = 0)
+    void bias_grad(std::vector<Fn>& ops, const LayerP& L, const char* g, int g_coff = 0, int nbatch = 1)
     {
         if (dry) return;
         const BufInfo& gb = pl.bi(g);
         const float* gp = pl.buf(g); float* part = pl.ws + pl.partial_off; float* db = pl.G + L.b;
-        const long npix = (long)gb.N * gb.H * gb.W; const int cs = gb.cs, C = L.cout;
+        const long npix = (long)gb.N * nbatch * gb.H * gb.W; const int cs = gb.cs, C = L.cout;
         ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_colsum(gp, npix, cs, g_coff, C, part, C <= 128 ? 512 : 256, db, 1, st); }, K_COLSUM));
     }
 
@@ -439,53 +443,59 @@ int build_decomposition_bwd(Builder& b, std::vector<Fn>& ops, const char* xin, i
     const LayerP Lr = layer(pl, d + "recon"), L7 = layer(pl, d + "conv7.0"), L5 = layer(pl, d + "conv5.0"), Ld = layer(pl, d + "deconv.0", true),
                  L3 = layer(pl, d + "conv3.0"), L2 = layer(pl, d + "conv2.0"), L1 = layer(pl, d + "conv1.0"), Ls = layer(pl, d + "shallow_conv.0"),
                  L0 = layer(pl, d + "conv0.0");
-    CK(b.wgrad(ops, Lr, 1, b.src(c7.c_str(), 64, H, W), 64, H, W, 0, "G8", 0, true));
-    CK(b.dgrad(ops, Lr, 1, "G8", 0, 0, 64, "G7", nullptr, 0, 0));
-    CK(b.wgrad(ops, L7, 1, b.src(c5.c_str(), 64, H, W), 64, H, W, 0, "G7"));
-    CK(b.wgrad(ops, L7, 1, b.src(c0.c_str(), 32, H, W), 32, H, W, 64, "G7", 0, true));
-    CK(b.dgrad(ops, L7, 1, "G7", 0, 0, 64, "G5", c5.c_str(), MASK_RELU, 0));
-    CK(b.dgrad(ops, L7, 1, "G7", 0, 64, 32, "G0", c0.c_str(), MASK_RELU, 0));
-    CK(b.wgrad(ops, L5, 1, b.src(dc.c_str(), 64, H, W), 64, H, W, 0, "G5"));
-    CK(b.wgrad(ops, L5, 1, b.src(c1.c_str(), 64, H, W), 64, H, W, 64, "G5", 0, true));
-    CK(b.dgrad(ops, L5, 1, "G5", 0, 0, 64, "Gdc", dc.c_str(), MASK_RELU, 0));
-    CK(b.dgrad(ops, L5, 1, "G5", 0, 64, 64, "G1", c1.c_str(), MASK_RELU, 0));
+    // gradient buffers of this pass; weight gradients are emitted by the pass-1 builder only, over [pass 1 ; pass 2]
+    // (pass 2 ran its data gradients earlier and left its G tensors in the second halves of the pairs)
+    auto gn = [&](const char* s) { return p == 1 ? std::string(s) : std::string(s) + "_2"; };
+    const std::string G8 = gn("G8"), G7 = gn("G7"), G5 = gn("G5"), G0 = gn("G0"), Gdc = gn("Gdc"), G3 = gn("G3"), G2 = gn("G2"),
+                      G1 = gn("G1"), Gsh = gn("Gsh");
+    const bool wg = p == 1;
+    if (wg) CK(b.wgrad(ops, Lr, 1, b.src("c7_1", 64, H, W), 64, H, W, 0, "G8", 0, true, 2));
+    CK(b.dgrad(ops, Lr, 1, G8.c_str(), 0, 0, 64, G7.c_str(), nullptr, 0, 0));
+    if (wg) CK(b.wgrad(ops, L7, 1, b.src("c5_1", 64, H, W), 64, H, W, 0, "G7", 0, false, 2));
+    if (wg) CK(b.wgrad(ops, L7, 1, b.src("c0_1", 32, H, W), 32, H, W, 64, "G7", 0, true, 2));
+    CK(b.dgrad(ops, L7, 1, G7.c_str(), 0, 0, 64, G5.c_str(), c5.c_str(), MASK_RELU, 0));
+    CK(b.dgrad(ops, L7, 1, G7.c_str(), 0, 64, 32, G0.c_str(), c0.c_str(), MASK_RELU, 0));
+    if (wg) CK(b.wgrad(ops, L5, 1, b.src("dc_1", 64, H, W), 64, H, W, 0, "G5", 0, false, 2));
+    if (wg) CK(b.wgrad(ops, L5, 1, b.src("c1_1", 64, H, W), 64, H, W, 64, "G5", 0, true, 2));
+    CK(b.dgrad(ops, L5, 1, G5.c_str(), 0, 0, 64, Gdc.c_str(), dc.c_str(), MASK_RELU, 0));
+    CK(b.dgrad(ops, L5, 1, G5.c_str(), 0, 64, 64, G1.c_str(), c1.c_str(), MASK_RELU, 0));
     // ConvTranspose2d: wgrad with swapped roles, dgrad = stride-2 conv of Gdc with W read as OIHW (O = ci, I = co)
-    if (!b.dry) {
+    if (!b.dry && wg) {
         SrcDesc gs = b.src("Gdc", 64, H, W);
         WgradParams wp; TapList t = ssie_taps_conv(3);
-        const BufInfo& cb = pl.bi(c3.c_str());
+        const BufInfo& cb = pl.bi("c3_1");
         const int sl = pl.slab_seq++ & 1;
         const size_t soff = sl ? pl.slab_off2 : pl.slab_off;
-        CK(ssie_make_wgrad(wp, gs, pl.N, H, W, 0, pl.buf(c3.c_str()), cb.cs, 0, 128, H2, W2, 2, t, pl.ws + soff, kWgs));
+        CK(ssie_make_wgrad(wp, gs, pl.N * 2, H, W, 0, pl.buf("c3_1"), cb.cs, 0, 128, H2, W2, 2, t, pl.ws + soff, kWgs));
         if (ssie_wgrad_slab_floats(wp) > pl.slab_cap) return SSIE_E_WORKSPACE;
         float* dw = pl.G + Ld.w; const float* slabs = pl.ws + soff;
-        ops.push_back(Fn([wp](hipStream_t st) { return ssie_launch_wgrad(wp, st); }, K_WGRAD, 2.0 * pl.N * H2 * W2 * 128.0 * 64 * 9, "", sl));
+        ops.push_back(Fn([wp](hipStream_t st) { return ssie_launch_wgrad(wp, st); }, K_WGRAD, 2.0 * pl.N * 2 * H2 * W2 * 128.0 * 64 * 9, "", sl));
         ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, wp.nslices, wp.ntaps, wp.ci_pad, wp.co_pad, 64, 128, dw, 64L * 9, 9, 1, nullptr, nullptr, 1, st); }, K_WGRAD_REDUCE, 0.0, "", sl));
     }
-    b.bias_grad(ops, Ld, "Gdc");
+    if (wg) b.bias_grad(ops, Ld, "Gdc", 0, 2);
     {
         TapList t = ssie_taps_conv(3);
         float* wpk = b.take_pack(ssie_packed_floats(64, 128, 9));
         if (!b.dry) {
             pl.packs.push_back(ssie_make_pack(pl.P + Ld.w, wpk, 64, 128, t, 9, 64 * 9, 1));
-            SrcDesc in = b.src("Gdc", 64, H, W);
+            SrcDesc in = b.src(Gdc.c_str(), 64, H, W);
             Epilogue e = b.bwd_epi(c3.c_str(), MASK_RELU, 0);
-            ConvParams cp; const BufInfo& ob = pl.bi("G3");
-            CK(ssie_make_conv(cp, &in, 1, pl.N, H, W, t, 2, H2, W2, wpk, 128, pl.buf("G3"), ob.H, ob.W, ob.cs, 0, 1, 0, 0, e));
+            ConvParams cp; const BufInfo& ob = pl.bi(G3.c_str());
+            CK(ssie_make_conv(cp, &in, 1, pl.N, H, W, t, 2, H2, W2, wpk, 128, pl.buf(G3.c_str()), ob.H, ob.W, ob.cs, 0, 1, 0, 0, e));
             b.push(ops, cp, 64);
         }
     }
-    CK(b.wgrad(ops, L3, 1, b.src(c2.c_str(), 128, H2, W2), 128, H2, W2, 0, "G3", 0, true));
-    CK(b.dgrad(ops, L3, 1, "G3", 0, 0, 128, "G2", c2.c_str(), MASK_RELU, 0));
-    CK(b.wgrad(ops, L2, 2, b.src(c1.c_str(), 64, H, W), 64, H, W, 0, "G2", 0, true));
-    CK(b.dgrad(ops, L2, 2, "G2", 0, 0, 64, "G1", c1.c_str(), MASK_RELU, 1));
-    CK(b.wgrad(ops, L1, 1, b.src(sh.c_str(), 64, H, W), 64, H, W, 0, "G1", 0, true));
-    CK(b.dgrad(ops, L1, 1, "G1", 0, 0, 64, "Gsh", nullptr, 0, 0));
-    CK(b.wgrad(ops, Ls, 1, b.src(xin, pl.CX, H, W), pl.B, H, W, 0, "Gsh", 0, true));
-    CK(b.wgrad(ops, L0, 1, b.src(xin, pl.CX, H, W), pl.B, H, W, 0, "G0", 0, true));
+    if (wg) CK(b.wgrad(ops, L3, 1, b.src("c2_1", 128, H2, W2), 128, H2, W2, 0, "G3", 0, true, 2));
+    CK(b.dgrad(ops, L3, 1, G3.c_str(), 0, 0, 128, G2.c_str(), c2.c_str(), MASK_RELU, 0));
+    if (wg) CK(b.wgrad(ops, L2, 2, b.src("c1_1", 64, H, W), 64, H, W, 0, "G2", 0, true, 2));
+    CK(b.dgrad(ops, L2, 2, G2.c_str(), 0, 0, 64, G1.c_str(), c1.c_str(), MASK_RELU, 1));
+    if (wg) CK(b.wgrad(ops, L1, 1, b.src("sh_1", 64, H, W), 64, H, W, 0, "G1", 0, true, 2));
+    CK(b.dgrad(ops, L1, 1, G1.c_str(), 0, 0, 64, Gsh.c_str(), nullptr, 0, 0));
+    if (wg) CK(b.wgrad(ops, Ls, 1, b.src("x", pl.CX, H, W), pl.B, H, W, 0, "Gsh", 0, true, 2));
+    if (wg) CK(b.wgrad(ops, L0, 1, b.src("x", pl.CX, H, W), pl.B, H, W, 0, "G0", 0, true, 2));
     if (input_grad) {
-        CK(b.dgrad(ops, Ls, 1, "Gsh", 0, 0, pl.B, "gS", nullptr, 0, 1));
-        CK(b.dgrad(ops, L0, 1, "G0", 0, 0, pl.B, "gS", nullptr, 0, 1));
+        CK(b.dgrad(ops, Ls, 1, Gsh.c_str(), 0, 0, pl.B, "gS", nullptr, 0, 1));
+        CK(b.dgrad(ops, L0, 1, G0.c_str(), 0, 0, pl.B, "gS", nullptr, 0, 1));
     }
     return 0;
 }
@@ -565,7 +575,7 @@ int build_all(Plan& pl, bool dry)
         LossParams lp; memset(&lp, 0, sizeof(lp));
         lp.x = pl.buf("x"); lp.x_cs = pl.CX; lp.RL = pl.buf("RL_1"); lp.rl_cs = pl.CRL; lp.D = pl.buf("D"); lp.d_cs = 4;
         lp.S = pl.buf("S"); lp.s_cs = pl.CX; lp.E = pl.buf("RL_2"); lp.e_cs = pl.CRL;
-        lp.gRL = pl.buf("gRL"); lp.gD = pl.buf("gD"); lp.gS = pl.buf("gS"); lp.G8b = pl.buf("G8");
+        lp.gRL = pl.buf("gRL"); lp.gD = pl.buf("gD"); lp.gS = pl.buf("gS"); lp.G8b = pl.buf("G8_2");
         lp.N = N; lp.H = H; lp.W = W; lp.B = B;
         lp.c_rec = pl.coefs[0]; lp.c_rf = pl.coefs[1]; lp.c_il = pl.coefs[2]; lp.c_id = pl.coefs[3]; lp.c_sp = pl.coefs[5];
         lp.a1 = pl.coefs[6]; lp.a2 = pl.coefs[7];
