@@ -21,8 +21,8 @@ def short(name):
 
 
 def find(d, pat):
-    f = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", d, "**", pat), recursive=True))
-    return f[-1] if f else None
+    f = glob.glob(os.path.join(ROOT, "gpurun_out", d, "**", pat), recursive=True)      # older runs' files stay in gpurun_out/
+    return max(f, key=os.path.getmtime) if f else None
 
 
 def main():
