@@ -1,18 +1,26 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path: full self-supervised train step (forward, six losses, hand-derived backward,
-fused Adam) on synthetic 128x128x31 hyperspectral patches, fp32, batch 32 per GPU (BASELINE.json configs[1];
-configs[3] = the same per GPU over N GPUs with one RCCL all-reduce of the flat gradient buffer).
+"""Benchmark of the hot path on synthetic hyperspectral cubes (inputs resident in HBM).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--workload train31|train256|infer1024_bf16|infer1024_f32]
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Rank 0 prints ONE JSON line.  `value` = patches/s over all ranks, inputs resident in HBM, max-over-ranks time
-around exactly K steps.  `roofline` = the dominant kernel class by device time, measured with HIP events after every
-launch in a profiled pass of the same step that follows the timed region (events inside the timed region would
-perturb `value`); `cpu_baseline` = the CPU oracle (a PyTorch port of the reference, which cannot travel to the GPU
-box) timed on this box's host cores on a bounded sample (batch 2 = the reference config's batch).
+workloads (BASELINE.json configs):
+  train31         configs[1] (default; configs[3] = the same per GPU over N GPUs, one RCCL all-reduce of the flat gradient
+                  buffer per step): full self-supervised train step (forward, six losses, hand-derived backward, fused Adam),
+                  batch 32 per GPU of 128x128x31 patches, fp32.  THE headline metric.
+  train256        configs[2]: the same step on 128x128x256-band cubes, batch 32 per GPU, fp32
+  infer1024_bf16  configs[4]: enhance-only forward (model.py:229-234) of one 1x31x1024x1024 cube, bf16 storage + bf16 MFMA
+                  (fp32 accumulate, fp32 outputs), whole image in one pass; a "step" = one image
+  infer1024_f32   the same forward in fp32 (what the bf16 line is compared with)
+
+Rank 0 prints ONE JSON line.  `value` = units/s over all ranks, max-over-ranks time around exactly K steps.
+`roofline` = the dominant kernel class by device time, from HIP events recorded after every launch in a profiled pass of
+the same step AFTER the timed region (events inside it would perturb `value`).  `parity` = the TIMED plan's own first step
+(the N = 32 plan, not a fresh small one) against the CPU oracle.  `cpu_baseline` = the CPU oracle (a PyTorch port of the
+reference, which cannot travel to the GPU box) on this box's host cores, bounded sample.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -22,9 +30,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 GFLOP_PER_PATCH = {(31, 128): 87.6, (31, 64): 21.9, (64, 128): 122.8, (256, 128): 327.6}   # SURVEY §8(d), full train step
+GFLOP_INFER_1024 = 1158.8          # 579.4 GMAC per 1024x1024x31 image incl. 34.4 GMAC attention
 PEAK_F32_TFLOPS = 157.3            # MI355X fp32 matrix (= vector) peak, MI355X_MICROARCH.md
+PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak
+PEAK_HBM_TBS = 8.0                 # HBM3E spec (6.3 TB/s achievable with float4 copies)
 JYU = dict(c_loss_reconstruction=10, c_loss_r_fidelity=1, c_loss_i_smooth_low=1, c_loss_i_smooth_delta=2000,
            c_loss_fourier=20, c_loss_spectral_cons=1, alpha_i_smooth_low=1, alpha_i_smooth_delta=10)   # config_outdoor_jyu.yml:24-31
+JYU_O = dict(c_rec=10.0, c_rf=1.0, c_il=1.0, c_id=2000.0, c_f=20.0, c_sp=1.0, alpha_low=1.0, alpha_delta=10.0)
 
 
 def synth(n, bands, hw, seed, device):
@@ -42,39 +54,48 @@ def synth(n, bands, hw, seed, device):
     return x.contiguous(memory_format=torch.channels_last).to(device)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="patches per GPU")
-    ap.add_argument("--bands", type=int, default=31)
-    ap.add_argument("--hw", type=int, default=128)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    args = ap.parse_args()
+def host_threads():
+    """the box gives one GPU job a 16-core CPU share; more threads than that only oversubscribe"""
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    return max(1, min(ncpu, int(os.environ.get("SSIE_CPU_THREADS", "16"))))
 
-    import torch
-    import ssie
-    ssie.load()
-    from ssie_amd import hostlib, model
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with WORLD_SIZE={args.gpus} (got {world})")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    assert hostlib.lib().ssie_device_ok() == 1, "bench.py needs a gfx950 (MI355X) device"
+def dominant_traffic(kernel_substr):
+    """HBM bytes per launch of ONE kernel (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc passes over this same
+    command, MI355X_MICROARCH.md HBM section) from the newest committed profile of THIS round; PMC counters cannot be read
+    from inside the process.  -> (bytes or None, kernel name, source file)"""
+    try:
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_*_hbm_traffic.json")))
+        for f in reversed(files):
+            tj = json.load(open(f))["kernels"]
+            cand = {k: v for k, v in tj.items() if kernel_substr in k}
+            if cand:
+                k = max(cand, key=lambda k: cand[k]["launches_sampled"] * cand[k]["hbm_bytes_per_launch"])
+                return int(cand[k]["hbm_bytes_per_launch"]), k, os.path.relpath(f, ROOT)
+    except Exception:
+        pass
+    return None, None, None
 
+
+def class_table(agg, reps):
+    out = {}
+    for k, v in agg.items():
+        ms, fl, cnt = v[0] / reps, v[1] / reps, v[2] // reps
+        e = {"ms_per_step": round(ms, 3), "launches": cnt,
+             "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if fl > 0 and ms > 0 else None}
+        out[k] = e
+    return out
+
+
+def run_train(args, torch, dist, hostlib, model, world, rank, dev):
+    bands, hw, batch = args.bands, args.hw, args.batch
     torch.manual_seed(41)                                   # reference default seed_value (main.py:19); same init on every rank
-    net = model.LowLightEnhance(input_channels=args.bands, lr=1e-3, **JYU).to(dev)
-    x = synth(args.batch, args.bands, args.hw, 41 + rank, dev)
+    net = model.LowLightEnhance(input_channels=bands, lr=1e-3, **JYU).to(dev)
+    x = synth(batch, bands, hw, 41 + rank, dev)
+    P0 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()} if rank == 0 else None
 
     def sync_all():
         torch.cuda.synchronize()
@@ -82,8 +103,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        net.train_step(x, world)
+    first = None
+    for i in range(args.warmup):
+        scal = net.train_step(x, world)
+        if i == 0 and rank == 0:                            # the timed plan's own first step, kept for the parity leg
+            first = (scal.clone(), net._plan_for(x).nchw("S", 0, bands).clone())
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -95,19 +119,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     losses = net._plan_for(x).loss_scalars().cpu().tolist()
-    value = world * args.batch * args.steps / dt
+    value = world * batch * args.steps / dt
 
     out = {
-        "metric": "HSI patches/sec (train step), 128x128x31", "value": round(value, 2), "unit": "patches/s",
+        "metric": f"HSI patches/sec (train step), {hw}x{hw}x{bands}", "value": round(value, 2), "unit": "patches/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"full self-supervised train step (fwd + 6 losses + bwd + Adam), batch {args.batch}/GPU of "
-                               f"{args.hw}x{args.hw}x{args.bands} patches, fp32, JYU loss coefficients",
-                   "global_batch": world * args.batch, "parallelism": f"dp{world}" if world > 1 else "single",
+        "config": {"workload": f"{args.workload}: full self-supervised train step (fwd + 6 losses + bwd + Adam), batch {batch}/GPU of "
+                               f"{hw}x{hw}x{bands} patches, fp32, JYU loss coefficients",
+                   "global_batch": world * batch, "parallelism": f"dp{world}" if world > 1 else "single",
                    "weights": "random init (PyTorch default), seed 41"},
         "final_total_loss": losses[0],
     }
-    gf = GFLOP_PER_PATCH.get((args.bands, args.hw))
+    gf = GFLOP_PER_PATCH.get((bands, hw))
     if gf:
         out["step_tflops_per_gpu"] = round(value / world * gf / 1e3, 2)
         out["step_frac_of_f32_peak"] = round(value / world * gf / 1e3 / PEAK_F32_TFLOPS, 4)
@@ -122,57 +146,211 @@ def main():
         dom = max(agg, key=lambda k: agg[k][0])
         ms, fl, cnt = agg[dom]
         ach = fl / (ms * 1e-3) / 1e12
-        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the per-launch figure
-        # comes from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (profiles/)
-        traffic = None
-        try:
-            import glob
-            tj = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))[-1]))["kernels"]
-            cand = [v["hbm_bytes_per_launch"] * v["launches_sampled"] for k, v in tj.items() if k.startswith("conv_fprop")]
-            nl = sum(v["launches_sampled"] for k, v in tj.items() if k.startswith("conv_fprop"))
-            traffic = int(sum(cand) / nl) if nl else None
-        except Exception:
-            pass
+        sub = "conv_wgrad_kernel" if "wgrad" in dom else "conv_fprop_v2w_kernel" if bands <= 64 else "conv_fprop_v2"
+        traffic, tk, tsrc = dominant_traffic(sub)
         out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic,
+                           "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic, "traffic_kernel": tk, "traffic_source": tsrc,
                            "launches_per_step": cnt // reps, "avg_launch_ms": round(ms / cnt, 4),
                            "algorithmic_gflop_per_step": round(fl / reps / 1e9, 1)}
-        out["kernel_classes"] = {k: {"ms_per_step": round(v[0] / reps, 3), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[1] > 0 and v[0] > 0 else None,
-                                     "launches": v[2] // reps} for k, v in agg.items()}
+        kc = class_table(agg, reps)
+        # HBM-bound classes: algorithmic bytes / device time (fused loss ~7 cubes + planes per patch; the Fourier
+        # term reads x, S and read-modify-writes gS; Adam 7 floats per parameter)
+        cube = batch * hw * hw * ((bands + 3) // 4 * 4) * 4
+        hbm_alg = {"loss_direct": 7 * cube + 5 * batch * hw * hw * 4, "fft_loss_kernel": 4 * cube}
+        for k, b in hbm_alg.items():
+            if kc.get(k, {}).get("ms_per_step"):
+                kc[k]["algorithmic_GBps"] = round(b / (kc[k]["ms_per_step"] * 1e-3) / 1e9, 1)
+                kc[k]["frac_of_hbm_peak"] = round(b / (kc[k]["ms_per_step"] * 1e-3) / 1e12 / PEAK_HBM_TBS, 3)
+        out["kernel_classes"] = kc
     if world > 1:
         sync_all()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # TEST-INFRASTRUCTURE import: the CPU oracle, used here only as the timed baseline and the PSNR checker
+        # TEST-INFRASTRUCTURE import: the CPU oracle, used here only as the parity checker and the timed baseline
         from collections import OrderedDict
         from oracle import ssie_oracle as O
-        # the box gives one GPU job a 16-core CPU share; more threads than that only oversubscribe
-        try:
-            ncpu = len(os.sched_getaffinity(0))
-        except AttributeError:
-            ncpu = os.cpu_count() or 1
-        ncpu = max(1, min(ncpu, int(os.environ.get("SSIE_CPU_THREADS", "16"))))
-        torch.set_num_threads(ncpu)
-        P = OrderedDict((k, v.detach().cpu().clone()) for k, v in net.state_dict().items())
+        torch.set_num_threads(host_threads())
+        if first is not None:
+            # parity of the TIMED configuration: first step of the N = batch plan vs compute_loss of the oracle on the same batch
+            with torch.no_grad():
+                _, vals, outs = O.compute_loss(P0, x.cpu(), JYU_O)
+            got = first[0].cpu().double().tolist()
+            rel = {k: abs(g - vals[k]) / max(abs(vals[k]), 1e-30) for k, g in zip(O.LOSS_KEYS, got)}
+            Sh = first[1].cpu()
+            out["parity"] = {"what": f"first train step of the timed N={batch} plan vs the CPU oracle on the same batch",
+                             "psnr_enhanced_vs_cpu_oracle_db": round(O.psnr(Sh, outs[3]), 1),
+                             "max_abs_S": float((Sh - outs[3]).abs().max()),
+                             "max_rel_err_7_losses": float(max(rel.values())),
+                             "total_loss_hip": got[0], "total_loss_oracle": vals["total_loss"]}
+            del outs
+        P = OrderedDict((k, v.clone()) for k, v in P0.items())
         xb = x[:2].cpu()
-        co = dict(c_rec=10.0, c_rf=1.0, c_il=1.0, c_id=2000.0, c_f=20.0, c_sp=1.0, alpha_low=1.0, alpha_delta=10.0)
-        with torch.no_grad():
-            So = O.enhance_forward(P, xb)[3]
-            Sh = net(x[:2].contiguous(memory_format=torch.channels_last))[3].cpu()
-        out["parity"] = {"psnr_enhanced_vs_cpu_oracle_db": round(O.psnr(Sh, So), 1),
-                         "max_abs_S": float((Sh - So).abs().max())}
         st = O.AdamState(P)
-        O.train_step(P, xb, co, st)                          # warm-up
+        O.train_step(P, xb, JYU_O, st)                          # warm-up
         t0 = time.perf_counter(); n = 0
         while n < 2 or (time.perf_counter() - t0 < 12.0 and n < 400):
-            P, *_ = O.train_step(P, xb, co, st); n += 1
+            P, *_ = O.train_step(P, xb, JYU_O, st); n += 1
         cdt = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": round(2 * n / cdt, 3), "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
-                               "sample": f"{n} full train steps of batch 2 (reference config batch) 128x128x{args.bands} on the CPU oracle "
+                               "sample": f"{n} full train steps of batch 2 (reference config batch) {hw}x{hw}x{bands} on the CPU oracle "
                                          f"(plain PyTorch restatement of the reference), {cdt:.1f} s"}
+    return out
+
+
+def infer_algorithmic_bytes(hw, bands, bf16):
+    """HBM floor of the enhance-only forward: every tensor of the op list written once and read once per consuming launch at its
+    storage precision (bf16 activations 2 B, the fp32 API tensors x / R|I / I_delta / S 4 B); concat / up-sampling never
+    materialise.  Channels per FULL-RES pixel: see DESIGN.md §3.5."""
+    a = 2 if bf16 else 4
+    px = hw * hw
+    cx, crl = (bands + 3) // 4 * 4, (bands + 4) // 4 * 4
+    full_w = 32 + 64 + 64 + 64 + 64 + 64 + 64 + 64 + 64          # c0 sh c1 dc c5 c7 | a0 d3 f
+    full_r = 32 + 64 + 2 * 64 + 64 + 64 + 64 + 2 * 64 + 2 * 64 + 64     # c1 feeds conv2 + conv5, a0 conv1 + skip, d3 fusion (+nothing)
+    half = (128 + 128 + 64 + 64) / 4.0                            # c2 c3 | a1 d2 at 1/2 resolution
+    low = (64 + 64) / 16.0 + 6 * 64 / 64.0                        # a2 d1 at 1/4; a3 qkv(3) ao f1 t3 at 1/8
+    act = (full_w + full_r + 2.5 * half + 3.0 * low) * a          # lower levels: ~1.5 - 2 reads per write
+    api = cx * 4 + (cx * a * 3 if bf16 else cx * 4) + crl * 4 * 2 + (crl * a * 2 if bf16 else crl * 4) + 4 * 3 + cx * 4
+    return px * (act + api)
+
+
+def run_infer(args, torch, hostlib, model, dev):
+    import ctypes as C
+    bands, hw = 31, args.hw
+    bf16 = args.workload.endswith("bf16")
+    torch.manual_seed(41)
+    net = model.LowLightEnhance(input_channels=bands, lr=1e-3, **JYU).to(dev)
+    x = synth(1, bands, hw, 41, dev)
+    net.bf16_inference = bf16
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            net._forward_views(x)            # the four outputs land in HBM; the reference's callers copy them to the host next
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            net._forward_views(x)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        S_dev = net._forward_views(x)[3].clone()
+    value = args.steps / dt
+    out = {
+        "metric": f"enhance-only images/sec, {hw}x{hw}x{bands}", "value": round(value, 2), "unit": "images/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: LowLightEnhance.forward (R, I, I_delta, S) of one 1x{bands}x{hw}x{hw} cube, whole image in one "
+                               f"pass (global attention over {(hw // 8) ** 2} tokens), "
+                               + ("bf16 storage + bf16 MFMA, fp32 accumulate / attention softmax / outputs" if bf16 else "fp32"),
+                   "global_batch": 1, "parallelism": "single", "weights": "random init (PyTorch default), seed 41"},
+    }
+    gflop = GFLOP_INFER_1024 * (hw / 1024.0) ** 2
+    out["step_tflops_per_gpu"] = round(value * gflop / 1e3, 2)
+    if not args.no_roofline:
+        plan = net._plan_for(x)
+        L = hostlib._proto()
+        cap = 1024
+        ms = (C.c_double * cap)(); fl = (C.c_double * cap)(); kinds = (C.c_int * cap)(); tags = C.create_string_buffer(1 << 16)
+        L.ssie_plan_profile_list.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_long), C.c_void_p, C.c_int, C.POINTER(C.c_double),
+                                             C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int, C.c_char_p, C.c_int]
+        agg = {}
+        reps = 3
+        for _ in range(reps):
+            n = L.ssie_plan_profile_list(plan.h, x.data_ptr(), plan._strides(x), torch.cuda.current_stream().cuda_stream, int(bf16),
+                                         ms, fl, kinds, cap, tags, 1 << 16)
+            assert n > 0, n
+            for i in range(n):
+                k = hostlib.Plan.KINDS[kinds[i]]
+                a = agg.setdefault(k, [0.0, 0.0, 0]); a[0] += ms[i]; a[1] += fl[i]; a[2] += 1
+        dom = max(agg, key=lambda k: agg[k][0])
+        dms, dfl, dcnt = agg[dom]
+        ach = dfl / (dms * 1e-3) / 1e12
+        peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
+        alg_bytes = infer_algorithmic_bytes(hw, bands, bf16)
+        t_mfma = gflop / 1e3 / peak * 1e3                       # ms
+        t_hbm = alg_bytes / (PEAK_HBM_TBS * 1e12) * 1e3
+        traffic, tk, tsrc = dominant_traffic("conv_fprop_bf16" if bf16 else "conv_fprop_v2")
+        out["roofline"] = {"kernel": dom, "bound": "mfma" if t_mfma >= t_hbm else "hbm", "achieved": round(ach, 2), "peak": peak,
+                           "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_kernel": tk, "traffic_source": tsrc,
+                           "launches_per_step": dcnt // reps, "avg_launch_ms": round(dms / dcnt, 4),
+                           "algorithmic_gflop_per_step": round(dfl / reps / 1e9, 1)}
+        step_ms = dt / args.steps * 1e3
+        out["floors"] = {"mfma_ms": round(t_mfma, 3), "hbm_ms": round(t_hbm, 3), "algorithmic_hbm_GB": round(alg_bytes / 1e9, 2),
+                         "binding": "mfma" if t_mfma >= t_hbm else "hbm",
+                         "frac_of_binding_floor": round(max(t_mfma, t_hbm) / step_ms, 4),
+                         "whole_image_tflops": round(gflop / step_ms, 1), "whole_image_GBps": round(alg_bytes / step_ms / 1e6, 1)}
+        out["kernel_classes"] = class_table(agg, reps)
+    if not args.no_cpu_baseline:
+        # TEST-INFRASTRUCTURE import: the CPU oracle as PSNR checker and timed baseline
+        from oracle import ssie_oracle as O
+        torch.set_num_threads(host_threads())
+        P = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+        xc = x.cpu()
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            So = O.enhance_forward(P, xc)[3]
+            c1 = time.perf_counter() - t0
+            n = 1
+            while time.perf_counter() - t0 < 15.0 and n < 5:
+                O.enhance_forward(P, xc); n += 1
+            cdt = time.perf_counter() - t0
+        Sh = S_dev.cpu()
+        out["parity"] = {"what": "enhanced cube S of the timed forward vs the fp32 CPU oracle (whole image)",
+                         "psnr_enhanced_vs_cpu_oracle_db": round(O.psnr(Sh, So), 1), "max_abs_S": float((Sh - So).abs().max())}
+        out["cpu_baseline"] = {"value": round(n / cdt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{n} whole-image forwards of 1x{bands}x{hw}x{hw} on the CPU oracle (fp32), {cdt:.1f} s"}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="train31", choices=["train31", "train256", "infer1024_bf16", "infer1024_f32"])
+    ap.add_argument("--batch", type=int, default=32, help="patches per GPU (train workloads)")
+    ap.add_argument("--bands", type=int, default=None)
+    ap.add_argument("--hw", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+    train = args.workload.startswith("train")
+    if args.bands is None:
+        args.bands = 256 if args.workload == "train256" else 31
+    if args.hw is None:
+        args.hw = 128 if train else 1024
+    args.warmup = max(args.warmup, 1)
+
+    import torch
+    import ssie
+    ssie.load()
+    from ssie_amd import dp, hostlib, model
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with WORLD_SIZE={args.gpus} (got {world})")
+    if not train and world > 1:
+        raise SystemExit("the enhance-only workloads do not shard: one image, one GPU (replicas only)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    # under torch.distributed.run the RCCL group is initialised even at world = 1, so that a 1-GPU launch exercises the same
+    # all-reduce / stream ordering as an N-GPU one
+    launched = "TORCHELASTIC_RUN_ID" in os.environ or world > 1
+    if launched:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dp.FORCE_COLLECTIVE = True
+    assert hostlib.lib().ssie_device_ok() == 1, "bench.py needs a gfx950 (MI355X) device"
+
+    if train:
+        out = run_train(args, torch, dist, hostlib, model, world, rank, dev)
+        out["rccl_group"] = bool(launched)
+    else:
+        out = run_infer(args, torch, hostlib, model, dev)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if launched:
         dist.destroy_process_group()
 
 

@@ -1,0 +1,45 @@
+/* Test / development entry points of libssie_hip.so.  NOT part of the drop-in boundary (include/ssie_hip.h): nothing in the
+ * product path calls these.  They exist so that `tests/` can force a specific kernel variant through the same parity cases,
+ * run the backward schedule on injected cotangents, and so that `tools/` can time single launches.
+ * The setters change process-global launch heuristics; tests restore the defaults (given in brackets) afterwards. */
+#ifndef SSIE_DEBUG_H
+#define SSIE_DEBUG_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* backward schedule only (everything ssie_plan_loss_fwd_bwd runs after the three loss kernels), on cotangents the caller
+ * wrote into the plan buffers "gRL", "gD", "gS", "G8_2" after a ssie_plan_loss_fwd_bwd call filled the activations */
+int ssie_plan_backward_from_cotangents(void* plan, void* stream);
+
+/* per-launch device ms / algorithmic FLOPs / kind in launch order of one train step; returns the op count (or -error) */
+int ssie_plan_profile_ops(void* plan, const float* x, const long* strides4, void* stream,
+                          double* ms, double* flops, int* kinds, int cap, char* tags, int tags_cap);
+/* per-launch timing of one op list; which = 0 fp32 enhance forward, 1 = bf16 enhance forward */
+int ssie_plan_profile_list(void* plan, const float* x, const long* strides4, void* stream, int which,
+                           double* ms, double* flops, int* kinds, int cap, char* tags, int tags_cap);
+/* launches per op list: {enhance forward, second decomposition pass, loss + backward} */
+int ssie_plan_num_ops(void* plan, int* counts3);
+
+/* launch heuristics */
+void ssie_debug_set_overlap(int on);                    /* [1] 0 = slab reductions in launch order on the caller's stream */
+void ssie_debug_set_fprop_min_tiles16(int v);           /* [256] launches with fewer 16x16 tiles use the 8x16 register-staged kernel */
+void ssie_debug_set_fprop_wide(int v);                  /* [1] 0 = no 16x32 tiles */
+void ssie_debug_set_fprop_wide_min_tiles(int v);        /* [512] */
+void ssie_debug_set_fprop_tile16(int v);                /* [1] */
+void ssie_debug_set_fprop_v2(int v);                    /* [1] 0 = never the 512-thread DMA kernel */
+void ssie_debug_set_fprop_v2_stride2(int v);            /* [1] */
+void ssie_debug_set_fprop_v2_split(int on);             /* [1] 0 = one 8-wave workgroup per CU for 32-channel layers too */
+void ssie_debug_set_fprop_v2_split_min_tiles(int v);    /* [1024] */
+void ssie_debug_set_fprop_wgs_per_cu(int v);
+void ssie_debug_set_wgrad_sliding(int v);               /* [1] 0 = generic wgrad K loop everywhere */
+/* (diagnostic builds compiled with -DSSIE_STAMP additionally export two s_memtime stamp-buffer setters, see tools/stamp_*.py;
+ * the shipped library has no stamp code) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

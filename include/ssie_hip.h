@@ -134,9 +134,26 @@ int ssie_plan_enhance_fwd_bf16(void* plan, const float* x, const long* strides4,
 
 /* compute_loss (+ loss.backward() when with_backward != 0): model.py:544-575, :315.  Writes "scalars";
  * with_backward also zeroes and fills the flat gradient buffer (zero_grad, model.py:313).
- * The Fourier term keeps one H x (W+1) complex plane in LDS (<= 160 KiB: up to 128 x 128; SSIE_E_SHAPE otherwise):
- * power-of-two sizes take the radix-2 path, other sizes (<= 192 per side) a direct DFT. */
+ * Any even patch size (model.py:456-473 takes any patch_size): the Fourier term keeps one H x (W+1) complex plane in LDS when
+ * it fits (<= 128 x 128; power-of-two sizes radix-2, other sizes up to 192 per side a direct DFT) and otherwise runs as three
+ * passes (rows, columns, rows) over a half-spectrum workspace inside the plan workspace. */
 int ssie_plan_loss_fwd_bwd(void* plan, const float* x, const long* strides4, int with_backward, void* stream);
+
+/* ---- standalone self-supervised loss operator (SURVEY §8(b) `selfsup_loss_fwd_bwd`) ------------------------------
+ * The six loss terms of model.py:551-555 on GIVEN tensors and their direct cotangents (what loss.backward(), model.py:315,
+ * hands to these five leaves): smooth_loss :450-454, fourier_spectrum_loss :456-473, spectral_smoothness_loss :475-481,
+ * structure_aware_loss :491-542, L_reconstruction :551.  All tensors NHWC with their own `*_cs` floats per pixel:
+ *   x, S (N,H,W,>=bands); RL = R_low in channels [0,bands) and I_low in channel `bands`; D = I_delta in channel 0;
+ *   E = R_enh in channels [0,bands) (buffer has > bands channels like RL).
+ * Outputs: gRL (geometry of RL: dL/dR_low | dL/dI_low), gD (geometry of D), gS (geometry of S), gE (geometry of E: dL/dR_enh,
+ * channel `bands` = 0), scalars7 = {total, L_reconstruction, L_R_fidelity, L_I_smooth_low, L_I_smooth_delta, L_fourier,
+ * L_spectral_cons} (device).  fourier_mask_dev = H*W bytes on the device, from ssie_fourier_mask(). */
+size_t ssie_selfsup_loss_workspace_bytes(int N, int bands, int H, int W);
+int ssie_selfsup_loss_fwd_bwd(const float* x, int x_cs, const float* RL, int rl_cs, const float* D, int d_cs,
+                              const float* S, int s_cs, const float* E, int e_cs,
+                              int N, int bands, int H, int W, const float* coefs8, const uint8_t* fourier_mask_dev,
+                              float* gRL, float* gD, float* gS, float* gE, float* scalars7,
+                              void* ws, size_t ws_bytes, void* stream);
 
 /* one compute_loss+backward with a HIP event after every launch: device milliseconds, algorithmic FLOPs and
  * launch counts per kernel class (synchronises; used by bench.py's roofline leg).  Arrays have 10 entries:
@@ -144,15 +161,6 @@ int ssie_plan_loss_fwd_bwd(void* plan, const float* x, const long* strides4, int
 #define SSIE_NKINDS 10
 int ssie_plan_profile_step(void* plan, const float* x, const long* strides4, void* stream,
                            double* ms, double* flops, int* counts);
-
-/* dev tool: per-launch device ms / algorithmic FLOPs / kind in launch order; returns the op count (or -error) */
-int ssie_plan_profile_ops(void* plan, const float* x, const long* strides4, void* stream,
-                          double* ms, double* flops, int* kinds, int cap, char* tags, int tags_cap);
-/* dev tool: per-launch timing of one op list; which = 0 fp32 enhance forward, 1 = bf16 enhance forward */
-int ssie_plan_profile_list(void* plan, const float* x, const long* strides4, void* stream, int which,
-                           double* ms, double* flops, int* kinds, int cap, char* tags, int tags_cap);
-/* launches per op list: {enhance forward, second decomposition pass, loss + backward} (dev tools) */
-int ssie_plan_num_ops(void* plan, int* counts3);
 
 /* torch.optim.Adam.step with default hyper-parameters (model.py:213, :316) over flat buffers;
  * grads are multiplied by grad_scale first (1/world_size after an all-reduce-sum) */

@@ -132,10 +132,19 @@ def synthetic_patches(n: int, bands: int, h: int, w: int, seed: int = 41, dtype=
 # --------------------------------------------------------------------------
 # model forward
 # --------------------------------------------------------------------------
-def _conv(x, P, key, stride=1, relu=False):
+def _relu(y, masks=None, name=None):
+    """nn.ReLU (model.py:21).  `masks` (tests only): {buffer name: bool tensor}; where given, the 0/1 decision comes from the
+    mask instead of sign(y).  tests/test_backward_gpu.py passes the HIP path's own decisions so that an fp64 evaluation of the
+    backward chain takes exactly the same branches as the fp32 one (they can differ where |y| ~ 1e-7)."""
+    if masks is not None and name in masks:
+        return y * masks[name].to(y.dtype)
+    return F.relu(y)
+
+
+def _conv(x, P, key, stride=1, relu=False, masks=None, name=None):
     w = P[key + ".weight"]
     y = F.conv2d(x, w, P[key + ".bias"], stride=stride, padding=(w.shape[-1] - 1) // 2)   # model.py:18-20
-    return F.relu(y) if relu else y
+    return _relu(y, masks, name) if relu else y
 
 
 def _rec(tr, tag, **kw):
@@ -148,24 +157,24 @@ def _rec(tr, tag, **kw):
         tr[k + tag] = v
 
 
-def decomposition(P, x, pre="decomposition_net.", tr=None, tag=""):
+def decomposition(P, x, pre="decomposition_net.", tr=None, tag="", masks=None):
     """model.py:49-70 -> (R, L)"""
     bands = x.shape[1]
-    c0 = _conv(x, P, pre + "conv0.0", relu=True)
+    c0 = _conv(x, P, pre + "conv0.0", relu=True, masks=masks, name="c0" + tag)
     sh = _conv(x, P, pre + "shallow_conv.0")
-    c1 = _conv(sh, P, pre + "conv1.0", relu=True)
-    c2 = _conv(c1, P, pre + "conv2.0", stride=2, relu=True)
-    c3 = _conv(c2, P, pre + "conv3.0", relu=True)
-    dc = F.relu(F.conv_transpose2d(c3, P[pre + "deconv.0.weight"], P[pre + "deconv.0.bias"],
-                                   stride=2, padding=1, output_padding=1))               # model.py:39-43
-    c5 = _conv(torch.cat([dc, c1], 1), P, pre + "conv5.0", relu=True)
+    c1 = _conv(sh, P, pre + "conv1.0", relu=True, masks=masks, name="c1" + tag)
+    c2 = _conv(c1, P, pre + "conv2.0", stride=2, relu=True, masks=masks, name="c2" + tag)
+    c3 = _conv(c2, P, pre + "conv3.0", relu=True, masks=masks, name="c3" + tag)
+    dc = _relu(F.conv_transpose2d(c3, P[pre + "deconv.0.weight"], P[pre + "deconv.0.bias"],
+                                  stride=2, padding=1, output_padding=1), masks, "dc" + tag)   # model.py:39-43
+    c5 = _conv(torch.cat([dc, c1], 1), P, pre + "conv5.0", relu=True, masks=masks, name="c5" + tag)
     c7 = _conv(torch.cat([c5, c0], 1), P, pre + "conv7.0")
     c8 = _conv(c7, P, pre + "recon")
     _rec(tr, tag, c0=c0, sh=sh, c1=c1, c2=c2, c3=c3, dc=dc, c5=c5, c7=c7, c8=c8)
     return torch.sigmoid(c8[:, :bands]), torch.sigmoid(c8[:, bands:])
 
 
-def attention_block(P, x, pre="illum_adjust_net.attn.", tr=None):
+def attention_block(P, x, pre="illum_adjust_net.attn.", tr=None, masks=None):
     """model.py:99-119; tokens = H*W, 4 heads x 16, no LayerNorm, residual on tokens."""
     n, c, h, w = x.shape
     s = h * w
@@ -175,7 +184,8 @@ def attention_block(P, x, pre="illum_adjust_net.attn.", tr=None):
                for nm in ("q_linear", "k_linear", "v_linear"))
     att = torch.softmax(q @ k.transpose(-2, -1) / (HEAD_DIM ** 0.5), dim=-1)
     o = (att @ v).permute(0, 2, 1, 3).reshape(n, s, HEADS * HEAD_DIM)
-    f1 = F.relu(lin(o, "ff_linear1"))
+    f1 = lin(o, "ff_linear1")
+    f1 = _relu(f1, None if masks is None or "f1" not in masks else {"f1": masks["f1"].reshape(n, c, s).permute(0, 2, 1)}, "f1")
     ff = lin(f1, "ff_linear2")
     _rec(tr, "", ao=o.permute(0, 2, 1).reshape(n, c, h, w), f1=f1.permute(0, 2, 1).reshape(n, c, h, w))
     return (tok + ff).permute(0, 2, 1).reshape(n, c, h, w)
@@ -185,18 +195,18 @@ def _up(x, like):
     return F.interpolate(x, size=like.shape[2:], mode="nearest")      # model.py:156,160,164,168,169
 
 
-def illum_adjust(P, I, R, pre="illum_adjust_net.", tr=None):
+def illum_adjust(P, I, R, pre="illum_adjust_net.", tr=None, masks=None):
     """model.py:143-175 -> I_delta (N,1,H,W); note cat order [R, I]."""
     c0 = _conv(torch.cat([R, I], 1), P, pre + "conv0.0")
-    c1 = _conv(c0, P, pre + "conv1.0", stride=2, relu=True)
-    c2 = _conv(c1, P, pre + "conv2.0", stride=2, relu=True)
-    c3 = _conv(c2, P, pre + "conv3.0", stride=2, relu=True)
-    t3 = attention_block(P, c3, pre + "attn.", tr)
-    u1 = _conv(_up(t3, c2), P, pre + "deconv1.0", relu=True)
+    c1 = _conv(c0, P, pre + "conv1.0", stride=2, relu=True, masks=masks, name="a1")
+    c2 = _conv(c1, P, pre + "conv2.0", stride=2, relu=True, masks=masks, name="a2")
+    c3 = _conv(c2, P, pre + "conv3.0", stride=2, relu=True, masks=masks, name="a3")
+    t3 = attention_block(P, c3, pre + "attn.", tr, masks)
+    u1 = _conv(_up(t3, c2), P, pre + "deconv1.0", relu=True, masks=masks, name="u1")
     d1 = u1 + c2
-    u2 = _conv(_up(d1, c1), P, pre + "deconv2.0", relu=True)
+    u2 = _conv(_up(d1, c1), P, pre + "deconv2.0", relu=True, masks=masks, name="u2")
     d2 = u2 + c1
-    u3 = _conv(_up(d2, c0), P, pre + "deconv3.0", relu=True)
+    u3 = _conv(_up(d2, c0), P, pre + "deconv3.0", relu=True, masks=masks, name="u3")
     d3 = u3 + c0
     gather = torch.cat([_up(d1, d3), _up(d2, d3), d3], 1)
     f = _conv(gather, P, pre + "feature_fusion.0")
@@ -204,10 +214,10 @@ def illum_adjust(P, I, R, pre="illum_adjust_net.", tr=None):
     return _conv(f, P, pre + "final_conv")
 
 
-def enhance_forward(P, x, tr=None):
+def enhance_forward(P, x, tr=None, masks=None):
     """model.py:229-234 -> (R_low, I_low, I_delta, S)"""
-    R, I = decomposition(P, x, tr=tr, tag="_1")
-    D = illum_adjust(P, I, R, tr=tr)
+    R, I = decomposition(P, x, tr=tr, tag="_1", masks=masks)
+    D = illum_adjust(P, I, R, tr=tr, masks=masks)
     S = R * D + R * I
     _rec(tr, "", R=R, I=I, D=D, S=S)
     return R, I, D, S
@@ -275,6 +285,21 @@ def loss_and_grads(P, x, coefs, tr=None):
     total.backward()
     grads = OrderedDict((k, (v.grad if v.grad is not None else torch.zeros_like(v))) for k, v in Pg.items())
     return vals, grads, tuple(o.detach() for o in outs)
+
+
+def grads_from_cotangents(P, x, cot, tr=None, masks=None):
+    """Backward chain alone (model.py:315 with the loss section replaced by FIXED direct cotangents): parameter gradients of the
+    linear surrogate <gR,R> + <gI,I> + <gD,D> + <gS,S> + <gE,E>, where cot = dict(gR, gI, gD, gS, gE) are constants and
+    (R, I, D, S) = forward(x), E = decomposition(S)[0] (model.py:545-546).  No sg() of a loss term is involved, so two
+    evaluations of this chain differ only by ordinary rounding (and ReLU decisions at |y| ~ 0: pass the other side's decisions as
+    `masks`, see _relu)."""
+    Pg = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in P.items())
+    R, I, D, S = enhance_forward(Pg, x, tr, masks)
+    E, _ = decomposition(Pg, S, tr=tr, tag="_2", masks=masks)
+    sur = sum((cot[k].to(t.dtype) * t).sum() for k, t in (("gR", R), ("gI", I), ("gD", D), ("gS", S), ("gE", E)))
+    sur.backward()
+    grads = OrderedDict((k, (v.grad if v.grad is not None else torch.zeros_like(v))) for k, v in Pg.items())
+    return grads, tuple(o.detach() for o in (R, I, D, S, E))
 
 
 # --------------------------------------------------------------------------

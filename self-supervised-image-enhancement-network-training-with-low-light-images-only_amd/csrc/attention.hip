@@ -159,8 +159,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 // operands of the second product are single 128-bit reads / register packs.  fp32 softmax and accumulation.
 typedef __bf16 at_bf16x8 __attribute__((ext_vector_type(8)));
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(at_bf16x8, (a)), __builtin_bit_cast(at_bf16x8, (b)), (c), 0, 0, 0)
-__device__ __forceinline__ unsigned at_f2bf(float f) { unsigned u = __float_as_uint(f); u += 0x7fffu + ((u >> 16) & 1u); return u >> 16; }
-__device__ __forceinline__ unsigned at_pack2(float a, float b) { return at_f2bf(a) | (at_f2bf(b) << 16); }
+__device__ __forceinline__ unsigned at_f2bf(float f) { return ssie_f2bf(f); }
+__device__ __forceinline__ unsigned at_pack2(float a, float b) { return ssie_pack2bf(a, b); }
 #define AV_LD 40         // Vt row: 32 bf16 keys padded to 40 (80 B): conflict-free 128-bit reads across the 16 dims
 
 __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const float* __restrict__ qkv, int qs, unsigned short* __restrict__ o, int os, int T, float scale)

@@ -21,12 +21,6 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),            \
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
-__device__ __forceinline__ unsigned short ssie_f2bf(float f)        // round to nearest even
-{
-    unsigned u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
 __device__ __forceinline__ float ssie_bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
 
 // source address of 8 consecutive bf16 channels of virtual pixel (n, vy, vx), or the zero page

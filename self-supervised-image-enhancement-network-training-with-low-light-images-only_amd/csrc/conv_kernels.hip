@@ -675,16 +675,13 @@ __device__ __forceinline__ void ssie_pack_one(const PackDesc& d, long idx4)
         unsigned w[4];
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {
-            unsigned pr = 0;
+            float f2[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int k = kb8 + 2 * s2 + e;
-                const float f = (k < d.K && n < d.N) ? d.w[(long)n * d.s_n + (long)k * d.s_k + ts] : 0.f;
-                unsigned u = __float_as_uint(f);
-                u += 0x7fffu + ((u >> 16) & 1u);
-                pr |= (u >> 16) << (16 * e);
+                f2[e] = (k < d.K && n < d.N) ? d.w[(long)n * d.s_n + (long)k * d.s_k + ts] : 0.f;
             }
-            w[s2] = pr;
+            w[s2] = ssie_pack2bf(f2[0], f2[1]);
         }
         f32x4 o = {__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3])};
         ((f32x4*)d.dst)[idx4] = o;

@@ -200,30 +200,269 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_loss_kernel(const FftParams p
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Planes that do not fit the LDS (training patches above 128 x 128, model.py:456-473 accepts any patch_size):
+// three passes over a half-spectrum workspace in HBM, every pass a batch of independent 1-D transforms in LDS.
+//   A  rows:    Z = FFT_W(x + i S) per row, split into the row spectra X^[h][kx], S^[h][kx] of the two REAL inputs,
+//               kx = 0..W/2 only (the other half is the conjugate), stored column-major  ws[plane][a][kx][h]
+//   B  columns: FFT_H of both -> F(x)[ky][kx], F(S)[ky][kx]; loss + g_Z per bin, weighted by M[k] + M[-k] on the interior
+//               columns (the mirror bin (-ky, W-kx) lives in the dropped half and has the same magnitudes; Re() of the
+//               adjoint makes its contribution the conjugate's - SURVEY §2.1 "cannot simply double"); inverse FFT_H
+//               in place -> G^[kx][h]
+//   C  rows:    gS[h][w] += Re sum_{kx <= W/2} G^[kx][h] e^{+2 pi i kx w / W}  (complex inverse with the upper half zero)
+// Power-of-two lengths use the radix-2 passes above, other lengths the direct DFT (out of place, any length).
+// ---------------------------------------------------------------------------------------------
+template <bool INVERSE>
+__device__ __forceinline__ void dft_lines(const float2* src, float2* dst, const float2* tw, int n, int lines, int es, int ls, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int line = wave; line < lines; line += FFT_THREADS / 64) {
+        const float2* sl = src + line * ls; float2* dl = dst + line * ls;
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            const int j = j0 + lane, jj = j % n;
+            float2 acc = make_float2(0.f, 0.f);
+            int idx = 0;
+            for (int k = 0; k < n; ++k) {
+                const float2 v = sl[k * es];
+                float2 w = tw[idx];
+                if (INVERSE) w.y = -w.y;
+                const float2 t = cmul(v, w);
+                acc.x += t.x; acc.y += t.y;
+                idx += jj; if (idx >= n) idx -= n;
+            }
+            if (j < n) dl[j * es] = acc;
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void fill_twiddles(float2* tw, int n, int count, int tid)
+{
+    for (int t = tid; t < count; t += FFT_THREADS) { float sn, cs; sincospif(-2.0f * (float)t / (float)n, &sn, &cs); tw[t] = make_float2(cs, sn); }
+}
+
+__device__ __forceinline__ int brev_n(int v, int logn) { return (int)(__brev((unsigned)v) >> (32 - logn)); }
+
+struct FftBigGeom { int R, logR, CB, logCB, WH, plane0, nplanes, row_tiles, col_groups; };
+
+// pass A.  grid = nplanes * row_tiles
+__global__ __launch_bounds__(FFT_THREADS) void fft_rows_fwd_kernel(const FftParams p, const FftBigGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const int tid = threadIdx.x, H = p.H, W = p.W, LS = W + 1, R = g.R;
+    const int pl = blockIdx.x / g.row_tiles, rt = blockIdx.x % g.row_tiles;
+    const int plane = g.plane0 + pl, n = plane / p.B, c = plane % p.B, h0 = rt * R;
+    const bool pow2 = p.logW >= 0;
+    float2* z = (float2*)smem_f;                       // [R][W+1]
+    float2* z2 = z + R * LS;                           // direct DFT only: output buffer
+    float2* tw = pow2 ? z2 : z2 + R * LS;
+    fill_twiddles(tw, W, pow2 ? (W >> 1) : W, tid);
+    const size_t base = (size_t)n * H * W;
+    for (int id = tid; id < R * W; id += FFT_THREADS) {
+        const int r = id / W, w = id - r * W, h = h0 + r;
+        float2 v = make_float2(0.f, 0.f);
+        if (h < H) { const size_t px = base + (size_t)h * W + w; v = make_float2(p.x[px * p.x_cs + c], p.S[px * p.s_cs + c]); }
+        z[r * LS + w] = v;
+    }
+    __syncthreads();
+    const float2* zo = z;
+    if (pow2) fft_pass<false>(z, tw, p.logW, W, p.logW, R, g.logR, 1, LS, tid);
+    else { dft_lines<false>(z, z2, tw, W, R, 1, LS, tid); zo = z2; }
+    float2* wsx = (float2*)p.ws + (size_t)pl * 2 * g.WH * H;
+    float2* wss = wsx + (size_t)g.WH * H;
+    for (int id = tid; id < R * g.WH; id += FFT_THREADS) {
+        const int r = id & (R - 1), kx = id >> g.logR, h = h0 + r;         // lanes along h: contiguous stores
+        if (h >= H) continue;
+        const int qx = kx ? W - kx : 0;
+        const float2 Zk = zo[r * LS + (pow2 ? brev_n(kx, p.logW) : kx)], Zm = zo[r * LS + (pow2 ? brev_n(qx, p.logW) : qx)];
+        wsx[(size_t)kx * H + h] = make_float2(0.5f * (Zk.x + Zm.x), 0.5f * (Zk.y - Zm.y));
+        wss[(size_t)kx * H + h] = make_float2(0.5f * (Zk.y + Zm.y), -0.5f * (Zk.x - Zm.x));
+    }
+}
+
+// pass B.  grid = nplanes * col_groups
+__global__ __launch_bounds__(FFT_THREADS) void fft_cols_kernel(const FftParams p, const FftBigGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const int tid = threadIdx.x, H = p.H, W = p.W, LS = H + 1, CB = g.CB;
+    const int pl = blockIdx.x / g.col_groups, cg = blockIdx.x % g.col_groups, kx0 = cg * CB;
+    const bool pow2 = p.logH >= 0;
+    float2* a = (float2*)smem_f;                       // [CB][H+1]  X^ -> F(x)
+    float2* b = a + CB * LS;                           // [CB][H+1]  S^ -> F(S) -> g_Z -> G^
+    float2* a2 = b + CB * LS; float2* b2 = a2 + CB * LS;      // direct DFT only
+    float2* tw = pow2 ? a2 : b2 + CB * LS;
+    float* red = (float*)(tw + (pow2 ? (H >> 1) : H));
+    fill_twiddles(tw, H, pow2 ? (H >> 1) : H, tid);
+    float2* wsx = (float2*)p.ws + (size_t)pl * 2 * g.WH * H;
+    float2* wss = wsx + (size_t)g.WH * H;
+    for (int id = tid; id < CB * H; id += FFT_THREADS) {
+        const int col = id / H, h = id - col * H, kx = kx0 + col;
+        float2 va = make_float2(0.f, 0.f), vb = va;
+        if (kx < g.WH) { va = wsx[(size_t)kx * H + h]; vb = wss[(size_t)kx * H + h]; }
+        a[col * LS + h] = va; b[col * LS + h] = vb;
+    }
+    __syncthreads();
+    float2* fa = a; float2* fb = b;
+    if (pow2) { fft_pass<false>(a, tw, p.logH, H, p.logH, CB, g.logCB, 1, LS, tid); fft_pass<false>(b, tw, p.logH, H, p.logH, CB, g.logCB, 1, LS, tid); }
+    else { dft_lines<false>(a, a2, tw, H, CB, 1, LS, tid); dft_lines<false>(b, b2, tw, H, CB, 1, LS, tid); fa = a2; fb = b2; }
+    float lsum = 0.f;
+    for (int id = tid; id < CB * H; id += FFT_THREADS) {
+        const int col = id / H, ky = id - col * H, kx = kx0 + col;
+        const int pos = col * LS + (pow2 ? brev_n(ky, p.logH) : ky);
+        float2 G = make_float2(0.f, 0.f);
+        if (kx < g.WH) {
+            const float2 Fx = fa[pos], Fs = fb[pos];
+            const float ax = sqrtf(Fx.x * Fx.x + Fx.y * Fx.y), as = sqrtf(Fs.x * Fs.x + Fs.y * Fs.y);
+            const float diff = ax - as;
+            float wgt = p.mask[ky * W + kx] ? 1.f : 0.f;
+            if (kx != 0 && 2 * kx != W) wgt += p.mask[(ky ? H - ky : 0) * W + (W - kx)] ? 1.f : 0.f;     // mirror bin in the dropped half
+            lsum += wgt * fabsf(diff);
+            const float coef = as > 0.f ? -((float)(diff > 0.f) - (float)(diff < 0.f)) * p.scale_g * wgt / as : 0.f;
+            G = make_float2(coef * Fs.x, coef * Fs.y);
+        }
+        fb[pos] = G;
+    }
+    __syncthreads();
+    const float2* go = fb;
+    if (pow2) fft_pass<true>(fb, tw, p.logH, H, p.logH, CB, g.logCB, 1, LS, tid);
+    else { dft_lines<true>(fb, b, tw, H, CB, 1, LS, tid); go = b; }
+    for (int id = tid; id < CB * H; id += FFT_THREADS) {
+        const int col = id / H, h = id - col * H, kx = kx0 + col;
+        if (kx < g.WH) wss[(size_t)kx * H + h] = go[col * LS + h];
+    }
+    for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+    if ((tid & 63) == 0) red[tid >> 6] = lsum;
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f;
+        for (int q = 0; q < FFT_THREADS / 64; ++q) s += red[q];
+        p.partials[(size_t)(g.plane0 + pl) * g.col_groups + cg] = s * p.inv_n0;
+    }
+}
+
+// pass C.  grid = nplanes * row_tiles
+__global__ __launch_bounds__(FFT_THREADS) void fft_rows_inv_kernel(const FftParams p, const FftBigGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const int tid = threadIdx.x, H = p.H, W = p.W, LS = W + 1, R = g.R;
+    const int pl = blockIdx.x / g.row_tiles, rt = blockIdx.x % g.row_tiles;
+    const int plane = g.plane0 + pl, n = plane / p.B, c = plane % p.B, h0 = rt * R;
+    const bool pow2 = p.logW >= 0;
+    float2* z = (float2*)smem_f;
+    float2* z2 = z + R * LS;
+    float2* tw = pow2 ? z2 : z2 + R * LS;
+    fill_twiddles(tw, W, pow2 ? (W >> 1) : W, tid);
+    const float2* wss = (const float2*)p.ws + (size_t)pl * 2 * g.WH * H + (size_t)g.WH * H;
+    for (int id = tid; id < R * W; id += FFT_THREADS) {
+        const int r = id & (R - 1), kx = id >> g.logR, h = h0 + r;
+        float2 v = make_float2(0.f, 0.f);
+        if (kx < g.WH && h < H) v = wss[(size_t)kx * H + h];
+        z[r * LS + (pow2 ? brev_n(kx, p.logW) : kx)] = v;
+    }
+    __syncthreads();
+    const float2* zo = z;
+    if (pow2) fft_pass<true>(z, tw, p.logW, W, p.logW, R, g.logR, 1, LS, tid);
+    else { dft_lines<true>(z, z2, tw, W, R, 1, LS, tid); zo = z2; }
+    const size_t base = (size_t)n * H * W;
+    for (int id = tid; id < R * W; id += FFT_THREADS) {
+        const int r = id / W, w = id - r * W, h = h0 + r;
+        if (h < H) p.gS[(base + (size_t)h * W + w) * p.s_cs + c] += zo[r * LS + w].x;
+    }
+}
+
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 static bool is_pow2(int v) { return v >= 2 && !(v & (v - 1)); }
 
-// 1: radix-2 path (power-of-two H and W), 2: direct-DFT path (any H, W <= 192), 0: the plane does not fit the 160 KiB LDS
+// 1: radix-2, plane in LDS (power-of-two H and W up to 128 x 128); 2: direct DFT, plane in LDS (any H, W <= 192 that fits);
+// 3: three-pass path through an HBM workspace (everything else up to 4096 per side); 0: unsupported
 int ssie_fft_supported(int H, int W)
 {
     if (H < 2 || W < 2) return 0;
     const bool p2 = is_pow2(H) && is_pow2(W);
-    if (!p2 && (H > 192 || W > 192)) return 0;
     size_t lds = (size_t)H * (W + 1) * 8 + (p2 ? (size_t)(H > W ? H : W) * 4 : (size_t)(H + W) * 8) + 64;
-    return lds <= 160 * 1024 ? (p2 ? 1 : 2) : 0;
+    if (lds <= 160 * 1024 && (p2 || (H <= 192 && W <= 192))) return p2 ? 1 : 2;
+    return (H <= 4096 && W <= 4096) ? 3 : 0;
+}
+
+void ssie_fft_set_logs(FftParams& p)
+{
+    const int kind = ssie_fft_supported(p.H, p.W);
+    if (kind == 1) { p.logH = ilog2(p.H); p.logW = ilog2(p.W); }
+    else if (kind == 3) { p.logH = is_pow2(p.H) ? ilog2(p.H) : -1; p.logW = is_pow2(p.W) ? ilog2(p.W) : -1; }   // per axis
+    else { p.logH = -1; p.logW = -1; }
 }
 
 int ssie_fft_grid(int N, int B) { return 8 * ((N + 7) / 8) * B; }
 
+namespace {
+const size_t kBigLdsBudget = 96 * 1024;
+const size_t kBigChunkBytes = 96u << 20;       // workspace of one plane chunk: small enough to stay in the 256 MiB Infinity Cache between passes
+int big_R(int W) { const bool p2 = is_pow2(W); int R = 16; while (R > 1 && (size_t)R * (W + 1) * 8 * (p2 ? 1 : 2) > kBigLdsBudget) R >>= 1; return R; }
+int big_CB(int H) { const bool p2 = is_pow2(H); int C = 16; while (C > 1 && (size_t)C * (H + 1) * 8 * (p2 ? 2 : 4) > kBigLdsBudget) C >>= 1; return C; }
+size_t big_plane_floats(int H, int W) { return (size_t)2 * (W / 2 + 1) * H * 2; }
+int big_chunk_planes(int N, int B, int H, int W)
+{
+    long c = (long)(kBigChunkBytes / (big_plane_floats(H, W) * 4)); if (c < 1) c = 1;
+    if (c > (long)N * B) c = (long)N * B;
+    return (int)c;
+}
+}
+
+// number of loss partial sums the Fourier kernels write (and the finalize kernel reads)
+int ssie_fft_partials(int N, int B, int H, int W)
+{
+    if (ssie_fft_supported(H, W) == 3) return N * B * ssie_ceil_div(W / 2 + 1, big_CB(H));
+    return ssie_fft_grid(N, B);
+}
+
+size_t ssie_fft_workspace_floats(int N, int B, int H, int W)
+{
+    if (ssie_fft_supported(H, W) != 3) return 0;
+    return (size_t)big_chunk_planes(N, B, H, W) * big_plane_floats(H, W);
+}
+
+static void allow_big_lds(const void* fn)
+{
+    static bool done[64] = {false};               // per (device, kernel): hipFuncSetAttribute is per device
+    static const void* fns[4] = {nullptr, nullptr, nullptr, nullptr};
+    int dev = 0; hipGetDevice(&dev);
+    int slot = 0; for (; slot < 4 && fns[slot] && fns[slot] != fn; ++slot) {}
+    if (slot == 4 || dev < 0 || dev >= 16) { hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return; }
+    fns[slot] = fn;
+    if (!done[dev * 4 + slot]) { hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done[dev * 4 + slot] = true; }
+}
+
+static int launch_fft_big(const FftParams& p, hipStream_t st)
+{
+    if (!p.ws) return 53;
+    FftBigGeom g;
+    g.R = big_R(p.W); g.logR = ilog2(g.R); g.CB = big_CB(p.H); g.logCB = ilog2(g.CB); g.WH = p.W / 2 + 1;
+    g.row_tiles = ssie_ceil_div(p.H, g.R); g.col_groups = ssie_ceil_div(g.WH, g.CB);
+    const bool p2w = p.logW >= 0, p2h = p.logH >= 0;
+    const size_t ldsA = (size_t)g.R * (p.W + 1) * 8 * (p2w ? 1 : 2) + (size_t)(p2w ? p.W / 2 : p.W) * 8 + 64;
+    const size_t ldsB = (size_t)g.CB * (p.H + 1) * 8 * (p2h ? 2 : 4) + (size_t)(p2h ? p.H / 2 : p.H) * 8 + 64 + FFT_THREADS / 64 * 4;
+    if (ldsA > 160 * 1024 || ldsB > 160 * 1024) return 54;
+    allow_big_lds((const void*)fft_rows_fwd_kernel); allow_big_lds((const void*)fft_cols_kernel); allow_big_lds((const void*)fft_rows_inv_kernel);
+    const int total = p.N * p.B, chunk = big_chunk_planes(p.N, p.B, p.H, p.W);
+    for (int p0 = 0; p0 < total; p0 += chunk) {
+        g.plane0 = p0; g.nplanes = total - p0 < chunk ? total - p0 : chunk;
+        hipLaunchKernelGGL(fft_rows_fwd_kernel, dim3(g.nplanes * g.row_tiles), dim3(FFT_THREADS), ldsA, st, p, g);
+        hipLaunchKernelGGL(fft_cols_kernel, dim3(g.nplanes * g.col_groups), dim3(FFT_THREADS), ldsB, st, p, g);
+        hipLaunchKernelGGL(fft_rows_inv_kernel, dim3(g.nplanes * g.row_tiles), dim3(FFT_THREADS), ldsA, st, p, g);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 55;
+}
+
 int ssie_launch_fft_loss(const FftParams& p, hipStream_t st)
 {
     const int kind = ssie_fft_supported(p.H, p.W);
-    if (!kind || (kind == 1) != (p.logH >= 0)) return 51;
+    if (!kind) return 51;
+    if (kind == 3) return launch_fft_big(p, st);
+    if ((kind == 1) != (p.logH >= 0)) return 51;
     const int M = p.H > p.W ? p.H : p.W;
     size_t lds = (size_t)p.H * (p.W + 1) * 8 + (kind == 1 ? (size_t)(M / 2) * 8 : (size_t)(p.H + p.W) * 8) + 64;
-    static bool set = false;
-    if (!set) { hipFuncSetAttribute((const void*)fft_loss_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    allow_big_lds((const void*)fft_loss_kernel);
     hipLaunchKernelGGL(fft_loss_kernel, dim3(ssie_fft_grid(p.N, p.B)), dim3(FFT_THREADS), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : 52;
 }

@@ -16,6 +16,7 @@ struct LossParams {
     float c_rec, c_rf, c_il, c_id, c_sp, a1, a2;
     float inv_n0, inv_nIx, inv_nIy, inv_nRx, inv_nRy, inv_nsp;
     float* partials;                 // [nblk][8]
+    int ge_raw;                      // 1: G8b receives dL/dR_enh itself (standalone operator); 0: times E(1-E), i.e. w.r.t. pass 2's pre-sigmoid output
 };
 
 struct FftParams {
@@ -26,7 +27,8 @@ struct FftParams {
     int N, B, H, W, logH, logW;
     float scale_g;                   // c_f / (N*B*H*W)
     float inv_n0;
-    float* partials;                 // [gridDim.x]
+    float* partials;                 // [ssie_fft_partials(N, B, H, W)]
+    float* ws;                       // three-pass path only: ssie_fft_workspace_floats(N, B, H, W) floats
 };
 
 int ssie_launch_loss_direct(const LossParams& p, int nblk, hipStream_t st);
@@ -46,5 +48,8 @@ int ssie_launch_adam(float* p, const float* g, float* m, float* v, long n, float
                      float b1, float b2, float eps, hipStream_t st);
 int ssie_fft_supported(int H, int W);
 int ssie_fft_grid(int N, int B);
+int ssie_fft_partials(int N, int B, int H, int W);
+size_t ssie_fft_workspace_floats(int N, int B, int H, int W);
+void ssie_fft_set_logs(FftParams& p);        // fills logH / logW for the path ssie_fft_supported(H, W) selects
 int ssie_launch_fft_loss(const FftParams& p, hipStream_t st);
 void ssie_fourier_mask_host(int H, int W, float cutoff, uint8_t* out);

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void loss_direct_kernel(const LossParams p)
             }
             gR += p.c_rf * gdel;
             p.gRL[pix * p.rl_cs + c] = gR;
-            p.G8b[pix * p.e_cs + c] = -p.c_rf * gdel * e0 * (1.f - e0);     // gE through pass-2's sigmoid
+            p.G8b[pix * p.e_cs + c] = p.ge_raw ? -p.c_rf * gdel : -p.c_rf * gdel * e0 * (1.f - e0);     // gE (through pass-2's sigmoid)
             // spectral TV on S (band axis = lane axis)
             const float s0 = p.S[pix * p.s_cs + c];
             float gs = 0.f;
@@ -337,10 +337,7 @@ __global__ void to_bf16_kernel(const f32x4* __restrict__ src, uint2* __restrict_
 {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const f32x4 v = src[i];
-        unsigned u[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { unsigned b = __float_as_uint(v[k]); b += 0x7fffu + ((b >> 16) & 1u); u[k] = b >> 16; }
-        dst[i] = make_uint2(u[0] | (u[1] << 16), u[2] | (u[3] << 16));
+        dst[i] = make_uint2(ssie_pack2bf(v[0], v[1]), ssie_pack2bf(v[2], v[3]));
     }
 }
 

@@ -15,6 +15,16 @@
 #define SSIE_TH 8            // output tile rows
 #define SSIE_TW 16           // output tile cols
 
+// fp32 -> bf16, round to nearest even, as a PLAIN CAST: hipcc emits v_cvt_pk_bf16_f32, which keeps a NaN a NaN (integer
+// rounding on the bit pattern turns some NaNs into 0 or infinity - MI355X_MICROARCH.md "Correctness boundaries")
+typedef __bf16 ssie_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned short ssie_f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ unsigned ssie_pack2bf(float lo, float hi)
+{
+    ssie_bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -13,6 +13,12 @@ import torch
 import torch.distributed as dist
 
 
+# When set (bench.py under torch.distributed.run), the gradient all-reduce is issued even at world size 1 so that a single-GPU
+# launch exercises RCCL initialisation, the collective's stream ordering against the backward's side-stream join and the
+# Adam scale exactly like an N-GPU launch does.
+FORCE_COLLECTIVE = False
+
+
 def init_from_env(backend: str | None = None):
     """(rank, world, local_rank); initialises torch.distributed from RANK/WORLD_SIZE/MASTER_* when world > 1."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -44,7 +50,7 @@ def rank_seed(seed: int, rank: int) -> int:
 
 def allreduce_flat_(flat_grads: torch.Tensor, world: int) -> float:
     """sum-all-reduce the flat gradient buffer in place; returns the scale (1/world) the optimiser must apply"""
-    if world > 1:
+    if world > 1 or (FORCE_COLLECTIVE and dist.is_initialized()):
         dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
     return 1.0 / world
 

@@ -200,7 +200,7 @@ def _enhance_whole(net, cube_hwc: np.ndarray):
     dev = next(net.parameters()).device
     x = torch.from_numpy(np.ascontiguousarray(cube_hwc)).to(dev).unsqueeze(0).permute(0, 3, 1, 2)
     with torch.no_grad():
-        R, I, D, S = net(x)
+        R, I, D, S = net._forward_views(x)          # copied to host right below: no need for owned device tensors
         to_np = lambda t: t.squeeze(0).permute(1, 2, 0).cpu().numpy()
         return to_np(R), to_np(I), to_np(D), to_np(S)
 

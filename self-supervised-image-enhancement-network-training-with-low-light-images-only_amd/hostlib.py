@@ -29,33 +29,28 @@ class SsieError(RuntimeError):
 
 
 def lib():
-    """Load (building in-tree if needed) libssie_hip.so; raises if that is impossible."""
+    """Load libssie_hip.so.  Load-only: building happens in `__graft_entry__.build()` / `python -m ssie_amd.build` BEFORE any
+    process touches the GPU (a GPU-initialised process must not spawn compiler children, and N ranks must not race on one
+    output file).  A missing or stale library is a loud error, never a fallback."""
     global _LIB
     if _LIB is not None:
         return _LIB
     path = _build.LIB
     if os.environ.get("SSIE_HIP_LIB"):       # dev switch for A/B runs of two builds inside one GPU session
         path = os.environ["SSIE_HIP_LIB"]
+    elif not os.path.exists(path):
+        raise SsieError(f"{path} is missing: build it first with `python -c 'import __graft_entry__ as g; g.build()'`")
     elif not _build.up_to_date():
-        if _build.hipcc() is None and not os.path.exists(path):
-            raise SsieError("libssie_hip.so is missing and hipcc is unavailable; run __graft_entry__.build()")
-        if _build.hipcc() is not None:
-            _build.build(verbose=False)
+        raise SsieError(f"{path} is older than its sources: rebuild with `python -c 'import __graft_entry__ as g; g.build()'`")
     L = C.CDLL(path)
     L.ssie_version.restype = C.c_char_p
     L.ssie_op_workspace_bytes.restype = C.c_size_t
-    if os.environ.get("SSIE_OVERLAP") is not None:      # dev switch: 0 = slab reductions in launch order on the main stream
-        L.ssie_debug_set_overlap(int(os.environ["SSIE_OVERLAP"]))
-    if os.environ.get("SSIE_MIN_TILES16") is not None:  # dev switch: threshold below which 8 x 16 tiles replace 16 x 16
-        L.ssie_debug_set_fprop_min_tiles16(int(os.environ["SSIE_MIN_TILES16"]))
-    if os.environ.get("SSIE_WGRAD_SLIDING") is not None:  # dev switch: 0 = generic wgrad K loop everywhere
-        L.ssie_debug_set_wgrad_sliding(int(os.environ["SSIE_WGRAD_SLIDING"]))
-    if os.environ.get("SSIE_V2_STRIDE2") is not None:   # dev switch: 0 = stride-2 layers on the register-staged kernel
-        L.ssie_debug_set_fprop_v2_stride2(int(os.environ["SSIE_V2_STRIDE2"]))
-    if os.environ.get("SSIE_WIDE") is not None:         # dev switch: 0 = no 16 x 32 tiles
-        L.ssie_debug_set_fprop_wide(int(os.environ["SSIE_WIDE"]))
-    if os.environ.get("SSIE_V2_SPLIT") is not None:     # dev switch: 0 = never split a CU between two 4-wave workgroups
-        L.ssie_debug_set_fprop_v2_split(int(os.environ["SSIE_V2_SPLIT"]))
+    # dev switches (include/ssie_debug.h); unset = the library's defaults
+    for env, fn in (("SSIE_OVERLAP", "ssie_debug_set_overlap"), ("SSIE_MIN_TILES16", "ssie_debug_set_fprop_min_tiles16"),
+                    ("SSIE_WGRAD_SLIDING", "ssie_debug_set_wgrad_sliding"), ("SSIE_V2_STRIDE2", "ssie_debug_set_fprop_v2_stride2"),
+                    ("SSIE_WIDE", "ssie_debug_set_fprop_wide"), ("SSIE_V2_SPLIT", "ssie_debug_set_fprop_v2_split")):
+        if os.environ.get(env) is not None:
+            getattr(L, fn)(int(os.environ[env]))
     _LIB = L
     return L
 
@@ -206,6 +201,11 @@ def _proto():
     L.ssie_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float,
                                  C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]
     L.ssie_fourier_mask.argtypes = [C.c_int, C.c_int, C.c_float, C.c_void_p]
+    L.ssie_plan_backward_from_cotangents.argtypes = [C.c_void_p, C.c_void_p]
+    L.ssie_selfsup_loss_workspace_bytes.restype = C.c_size_t
+    L.ssie_selfsup_loss_workspace_bytes.argtypes = [C.c_int] * 4
+    L.ssie_selfsup_loss_fwd_bwd.argtypes = ([C.c_void_p, C.c_int] * 5 + [C.c_int] * 4 + [C.POINTER(C.c_float), C.c_void_p]
+                                            + [C.c_void_p] * 5 + [C.c_void_p, C.c_size_t, C.c_void_p])
     L.ssie_plan_profile_step.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_long), C.c_void_p,
                                          C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
     return L
@@ -293,12 +293,22 @@ class Plan:
         check(self.L.ssie_plan_enhance_fwd(self.h, x.data_ptr(), self._strides(x), torch.cuda.current_stream().cuda_stream),
               "ssie_plan_enhance_fwd")
 
+    def has_bf16(self) -> bool:
+        """the bf16 enhance-only list exists for this band count (padded B and B+1 multiples of 8, e.g. 31, 63, 127)"""
+        b = self.shape[1]
+        return ((b + 3) // 4 * 4) % 8 == 0 and ((b + 4) // 4 * 4) % 8 == 0
+
     def loss_fwd_bwd(self, x, backward=True):
         check(self.L.ssie_plan_loss_fwd_bwd(self.h, x.data_ptr(), self._strides(x), int(backward),
                                             torch.cuda.current_stream().cuda_stream), "ssie_plan_loss_fwd_bwd")
 
     def loss_scalars(self) -> torch.Tensor:
         return self.buffer("scalars").reshape(7)
+
+    def backward_from_cotangents(self):
+        """TEST ENTRY (include/ssie_debug.h): backward schedule only, on cotangents written into gRL / gD / gS / G8_2"""
+        check(self.L.ssie_plan_backward_from_cotangents(self.h, torch.cuda.current_stream().cuda_stream),
+              "ssie_plan_backward_from_cotangents")
 
     KINDS = ("conv_fprop(+dgrad) 64-ch tile", "conv_fprop(+dgrad) 32-ch tile", "conv_wgrad_kernel", "wgrad_reduce_kernel", "colsum",
              "pack_weights", "loss_direct", "fft_loss_kernel", "attention", "elementwise")
@@ -309,6 +319,29 @@ class Plan:
         check(self.L.ssie_plan_profile_step(self.h, x.data_ptr(), self._strides(x), torch.cuda.current_stream().cuda_stream,
                                             ms, fl, cnt), "ssie_plan_profile_step")
         return {k: (ms[i], fl[i], cnt[i]) for i, k in enumerate(self.KINDS)}
+
+
+def selfsup_loss_fwd_bwd(x, R, I, D, S, E, coefs: dict):
+    """Standalone loss operator (ssie_selfsup_loss_fwd_bwd) on logical (N,C,H,W) cuda tensors.
+    -> (scalars7 device tensor, dict(gR, gI, gD, gS, gE) as logical (N,C,H,W) tensors)"""
+    L = _proto()
+    n, b, h, w = x.shape
+    dev = x.device
+    xb, Sb, Db = nhwc(x), nhwc(S), nhwc(D)
+    RLb = nhwc(torch.cat([R, I], 1))
+    Eb = nhwc(torch.cat([E, torch.zeros_like(I)], 1))
+    gRL, gD, gS, gE = torch.zeros_like(RLb), torch.zeros_like(Db), torch.zeros_like(Sb), torch.zeros_like(Eb)
+    scal = torch.zeros(8, device=dev)
+    mask = torch.from_numpy(fourier_mask(h, w)).to(dev)
+    nbytes = L.ssie_selfsup_loss_workspace_bytes(n, b, h, w)
+    ws = torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+    cf = (C.c_float * 8)(*[float(coefs[k]) for k in COEF_ORDER])
+    check(L.ssie_selfsup_loss_fwd_bwd(xb.data_ptr(), xb.shape[3], RLb.data_ptr(), RLb.shape[3], Db.data_ptr(), Db.shape[3],
+                                      Sb.data_ptr(), Sb.shape[3], Eb.data_ptr(), Eb.shape[3], n, b, h, w, cf, mask.data_ptr(),
+                                      gRL.data_ptr(), gD.data_ptr(), gS.data_ptr(), gE.data_ptr(), scal.data_ptr(),
+                                      ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream), "ssie_selfsup_loss_fwd_bwd")
+    nc = lambda t, c0, c1: t[..., c0:c1].permute(0, 3, 1, 2)
+    return scal[:7], dict(gR=nc(gRL, 0, b), gI=nc(gRL, b, b + 1), gD=nc(gD, 0, 1), gS=nc(gS, 0, b), gE=nc(gE, 0, b))
 
 
 def adam_step(params, grads, m, v, step, lr, grad_scale=1.0, b1=0.9, b2=0.999, eps=1e-8):

@@ -44,20 +44,33 @@ class FusedAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0):
+        """torch.optim.Adam.step semantics: a parameter whose .grad is None (frozen, model.py:274-279) is skipped entirely -
+        no moment decay, no update.  Parameters with gradients are stepped in contiguous runs of the flat buffer (one launch
+        when nothing is frozen)."""
         o = self._owner
         o._ensure_device_layout()
         flat, gflat = o._flat, o._gflat
-        # gradients that autograd materialised outside the flat buffer are copied back in
+        runs = []                                     # [start, end) float ranges of the flat buffer that have gradients
         for (name, off, shape), p in zip(o._table, o._plist):
             n = p.numel()
             if p.grad is None:
-                gflat[off:off + n].zero_()
-            elif p.grad.data_ptr() != gflat.data_ptr() + 4 * off:
+                continue
+            if p.grad.data_ptr() != gflat.data_ptr() + 4 * off:      # autograd materialised it outside the flat buffer
                 gflat[off:off + n].copy_(p.grad.reshape(-1))
+            end = (off + n + 3) // 4 * 4                               # tensors are 16-byte aligned: pad floats are zero
+            if runs and runs[-1][1] == off:
+                runs[-1][1] = end
+            else:
+                runs.append([off, end])
+        if not runs:
+            return
         m, v = self._buffers()
         g = self.param_groups[0]
         self.step_count += 1
-        H.adam_step(flat, gflat, m, v, self.step_count, float(g["lr"]), grad_scale, g["betas"][0], g["betas"][1], g["eps"])
+        for a, b in runs:
+            b = min(b, flat.numel())
+            H.adam_step(flat[a:b], gflat[a:b], m[a:b], v[a:b], self.step_count, float(g["lr"]), grad_scale,
+                        g["betas"][0], g["betas"][1], g["eps"])
 
     def reset_state(self):
         """what re-creating torch.optim.Adam does (model.py:284): moments and step count start over"""
@@ -149,6 +162,7 @@ class LowLightEnhance(nn.Module):
         # opt-in (not a reference kwarg): forward() under torch.no_grad() uses bf16 storage + bf16 MFMA; outputs stay fp32
         self.bf16_inference = False
         self.max_cached_plans = 4
+        self._warned_forward_grad = False
         self.all_epoch_losses = {k: [] for k in LOSS_KEYS}
 
         self._table, total = H.param_table(input_channels)
@@ -245,11 +259,27 @@ class LowLightEnhance(nn.Module):
 
     # ---- reference API ------------------------------------------------------------------------
     def forward(self, input_low):
-        """model.py:229-234.  Returns views into the plan workspace (valid until the next call on this shape)."""
+        """model.py:229-234 -> (R_low, I_low, I_delta, S), tensors the caller owns (like the reference's).
+        The four outputs carry NO autograd graph: the backward pass of this build is the hand-derived one inside
+        `compute_loss` / `train_step`.  Calling forward with grad enabled on trainable parameters therefore warns once."""
+        R, I, D, S = self._forward_views(input_low)
+        if torch.is_grad_enabled() and not self._warned_forward_grad and any(p.requires_grad for p in self._plist):
+            import warnings
+            warnings.warn("LowLightEnhance.forward() returns tensors without an autograd graph: a loss built on them yields no "
+                          "parameter gradients.  Use compute_loss()/train_step() (hand-derived backward), or call forward "
+                          "under torch.no_grad().", stacklevel=2)
+            self._warned_forward_grad = True
+        return R.clone(), I.clone(), D.clone(), S.clone()
+
+    def _forward_views(self, input_low):
+        """forward without the copies: views into the plan workspace, valid until the next call on this input shape
+        (internal: harness and tests)."""
         x = self._f32(input_low)
         plan = self._plan_for(x)
-        # mixed-precision inference (BASELINE.json configs[4]): only outside autograd, training always runs fp32
-        plan.enhance_fwd(x, bf16=bool(self.bf16_inference) and not torch.is_grad_enabled())
+        # mixed-precision inference (BASELINE.json configs[4]): only outside autograd, training always runs fp32;
+        # band counts the bf16 list cannot take (B+1 not a multiple of 8 after padding) use the fp32 path
+        bf16 = bool(self.bf16_inference) and not torch.is_grad_enabled() and plan.has_bf16()
+        plan.enhance_fwd(x, bf16=bf16)
         b = self.input_channels
         return plan.nchw("RL_1", 0, b), plan.nchw("RL_1", b, b + 1), plan.nchw("D", 0, 1), plan.nchw("S", 0, b)
 
@@ -273,27 +303,59 @@ class LowLightEnhance(nn.Module):
         x = self._f32(input_low)
         plan = self._plan_for(x)
         plan.loss_fwd_bwd(x, backward=True)
-        if self._decomp_frozen:
-            self._gflat[:self._illum_off].zero_()                # frozen DecompositionNet (model.py:274-279): no update
+        return self._finish_step(world_size, plan.loss_scalars())
+
+    def _finish_step(self, world_size, scalars=None):
+        """tail of a train step on the flat gradient buffer: frozen range -> (RCCL) all-reduce -> fused Adam with the 1/world
+        scale.  Frozen DecompositionNet (model.py:274-279): the reference leaves those parameters with grad None, so
+        torch's Adam skips them - no update AND no moment decay; here Adam runs only on the illumination-net range."""
         gscale = dp.allreduce_flat_(self._gflat, world_size)   # one flat fp32 buffer over RCCL / xGMI
         opt = self.optimizer
         m, v = opt._buffers()
         g = opt.param_groups[0]
         opt.step_count += 1
         opt._opt_called = True                                   # lets torch's StepLR know a step happened
-        H.adam_step(self._flat, self._gflat, m, v, opt.step_count, float(g["lr"]), gscale,
+        a = self._illum_off if self._decomp_frozen else 0
+        H.adam_step(self._flat[a:], self._gflat[a:], m[a:], v[a:], opt.step_count, float(g["lr"]), gscale,
                     g["betas"][0], g["betas"][1], g["eps"])
-        return plan.loss_scalars()
+        return scalars
 
     def set_decomposition_frozen(self, frozen: bool):
         """freeze_decom_epochs semantics (model.py:274-288): frozen => DecompositionNet gets no updates; on the
-        frozen -> unfrozen transition the reference re-creates Adam, i.e. all optimiser state starts over."""
+        frozen -> unfrozen transition the reference re-creates Adam AND StepLR with the current lr (model.py:284-286),
+        i.e. all optimiser state and the lr-decay period start over."""
         frozen = bool(frozen)
         if self._decomp_frozen and not frozen:
             self.optimizer.reset_state()
+            if self.adaptive_lr:
+                g = self.optimizer.param_groups[0]
+                g.pop("initial_lr", None)                          # a fresh optimiser has none: StepLR restarts from the current lr
+                self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=self.lr_update_period,
+                                                                 gamma=self.lr_update_factor)
         self._decomp_frozen = frozen
         for p in self.decomposition_net.parameters():
             p.requires_grad = not frozen
+
+    # ---- the reference's harness methods (model.py:236, :343, :406), same argument names -----------------------------
+    def train_model(self, train_data_path, eval_data_path, batch_size, patch_size, num_epochs, start_lr, ckpt_dir,
+                    eval_result_dir, eval_every_epoch, label_dir, plot_every_epoch=10):
+        """model.py:236-341 (called at main.py:92-105).  `start_lr` is only logged by the reference (model.py:258);
+        `plot_every_epoch` drives matplotlib curves that are out of scope here."""
+        from . import harness
+        return harness.train_model(self, train_data_path, eval_data_path, batch_size, patch_size, num_epochs, ckpt_dir,
+                                   eval_result_dir, eval_every_epoch, label_dir)
+
+    def evaluate_model(self, eval_low_data, eval_files, eval_result_dir, epoch, label_dir):
+        """model.py:343-404"""
+        from . import harness
+        return harness.evaluate_model(self, eval_low_data, eval_files, eval_result_dir, epoch, label_dir)
+
+    def test_model(self, model_dir, test_low_data, test_low_data_names, save_dir, save_reflectance=False,
+                   save_illumination=False, save_i_delta=False):
+        """model.py:406-443 (called at main.py:120-128)"""
+        from . import harness
+        return harness.test_model(self, model_dir, test_low_data, test_low_data_names, save_dir, save_reflectance,
+                                  save_illumination, save_i_delta)
 
     def flat_parameters(self):
         self._ensure_device_layout()

@@ -9,6 +9,9 @@ writes reference OUTPUTS (data only) to tests/golden/*.npz:
   case_b31_32  N=2 B=31 32x32   JYU coefs     : strided sub-samples + fp64 checksums of R,I,D,S,E, 7 losses, grad norms + small grads (others ::53), params after 1 & 3 steps
   case_b31_64  N=2 B=31 64x64   JYU coefs     : strided sub-samples + fp64 checksums, 7 losses, grad norms
   aux          Fourier masks (16/64/128), nearest-upsample index vectors, crop+augment patches
+  hsi_raw.mat  a small raw cube written by the reference's utils.save_hsi (utils.py:171-178)
+  io           utils.load_hsi (utils.py:36-57) of that file in every normalisation mode (None, self, global with min 238 /
+               max 4095 - values below the min clamp to 0 -, global with min None, per-channel normalisation / standardisation)
 
 The logging/plot dependencies the reference imports at module top (mlflow, torchinfo,
 torchmetrics, skimage) are not installed here and are not on the hot path; empty module
@@ -153,9 +156,38 @@ def run_aux(ref_model, ref_utils):
     print("aux ->", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
 
+def run_io(ref_utils):
+    """N2: the on-disk format either side of the path.  Raw cube = integer-hash values in [100, 4500): below global_min 238
+    (negative after the shift -> clamped) and above global_max 4095 (> 1 before the second normalisation)."""
+    raw = (100.0 + 4400.0 * O._hash_uniform(14 * 12 * 6, 777).reshape(14, 12, 6)).astype("float32")
+    raw[3, 4, :] = raw[3, 4, 0]                      # a constant pixel; channel 5 constant -> per-channel range/std guards
+    raw[:, :, 5] = 1234.0
+    path = os.path.join(HERE, "hsi_raw.mat")
+    ref_utils.save_hsi(path, raw)                    # reference writer
+    out = {"raw": raw}
+    out["none"] = ref_utils.load_hsi(path)
+    out["self"] = ref_utils.load_hsi(path, "data", "self")
+    out["global_238_4095"] = ref_utils.load_hsi(path, "data", "global_normalization", 4095.0, 238.0)
+    out["global_none_4095"] = ref_utils.load_hsi(path, "data", "global_normalization", 4095.0, None)
+    out["per_channel_normalization"] = ref_utils.load_hsi(path, "data", "per_channel_normalization")
+    out["per_channel_standardization"] = ref_utils.load_hsi(path, "data", "per_channel_standardization")
+    # postfix form of save_hsi (model.py:431-439 artifacts): file name only
+    tmp = os.path.join(HERE, "_tmp_io.mat")
+    ref_utils.save_hsi(tmp, raw[:2, :2], postfix="_R_low", key="data")
+    assert os.path.exists(tmp[:-4] + "_R_low.mat")
+    os.remove(tmp[:-4] + "_R_low.mat")
+    p = os.path.join(HERE, "io.npz")
+    np.savez_compressed(p, **out)
+    print("io ->", p, "%.1f KB" % (os.path.getsize(p) / 1024), {k: (v.dtype, float(v.max())) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     ref_model, ref_utils = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "io":
+        run_io(ref_utils)
+        sys.exit(0)
     run_case(ref_model, "case_b5_16", 1, 5, 16, O.DEFAULT_COEFS, full=True)
     run_case(ref_model, "case_b31_32", 2, 31, 32, O.JYU_COEFS, full=False)
     run_case(ref_model, "case_b31_64", 2, 31, 64, O.JYU_COEFS, full=False)
     run_aux(ref_model, ref_utils)
+    run_io(ref_utils)

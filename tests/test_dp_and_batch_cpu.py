@@ -72,6 +72,63 @@ def test_dp_two_ranks_equal_single_rank_on_concatenated_batch(tmp_path):
         assert (got - ref).norm().item() <= tol * ref.norm().item() + 1e-12, (name, tol)
 
 
+def _adam_double(params, grads, m, v, step, lr, grad_scale=1.0, b1=0.9, b2=0.999, eps=1e-8):
+    """test double for the HIP Adam launch (hostlib.adam_step) with the same argument contract, in place on the views"""
+    g = grads * grad_scale
+    m.mul_(b1).add_(g, alpha=1 - b1); v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    params.sub_((lr / (1 - b1 ** step)) * m / (v.sqrt() / np.sqrt(1 - b2 ** step) + eps))
+
+
+def _tail_worker(rank, world, port, bands, hw, out_dir, frozen):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    import ssie
+    ssie.load()
+    from ssie_amd import dp, hostlib as H, model as M
+    dp.init_from_env("gloo")
+    H.adam_step = _adam_double                                     # the only HIP launch in the tail
+    net = M.LowLightEnhance(input_channels=bands, lr=1e-3)
+    P = O.closed_form_params(bands)
+    net.load_state_dict(P)
+    net._ensure_device_layout()
+    net.set_decomposition_frozen(frozen)
+    x = O.synthetic_patches(4, bands, hw, hw)
+    mine = dp.shard_range(4, rank, world)
+    _, grads, _ = O.loss_and_grads(P, x[mine.start:mine.stop], O.JYU_COEFS)
+    for (name, off, shape), p in zip(net._table, net._plist):
+        net._gflat[off:off + p.numel()] = grads[name].reshape(-1)          # what the HIP backward leaves in the flat buffer
+    net._finish_step(world)                                              # PRODUCT CODE: frozen range -> all-reduce -> scaled Adam
+    if rank == 0:
+        torch.save({k: v.detach().clone() for k, v in net.state_dict().items()}, os.path.join(out_dir, f"tail_{int(frozen)}.pt"))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("frozen", [False, True])
+def test_train_step_tail_two_ranks(tmp_path, frozen):
+    """`LowLightEnhance._finish_step` (the part of train_step after the HIP backward) over gloo, world 2: parameters after the
+    step == one Adam step on the gradient of the concatenated batch; with a frozen DecompositionNet its parameters do not move
+    (model.py:274-279).  The Adam launch is replaced by a torch double with the same argument contract."""
+    bands, hw = 5, 16
+    port = _free_port()
+    mp.spawn(_tail_worker, args=(2, port, bands, hw, str(tmp_path), frozen), nprocs=2, join=True)
+    got = torch.load(os.path.join(tmp_path, f"tail_{int(frozen)}.pt"), weights_only=True)
+    P = O.closed_form_params(bands)
+    x = O.synthetic_patches(4, bands, hw, hw)
+    _, g0, _ = O.loss_and_grads(P, x[:2], O.JYU_COEFS)
+    _, g1, _ = O.loss_and_grads(P, x[2:], O.JYU_COEFS)
+    for k in P:
+        if frozen and k.startswith("decomposition_net."):
+            assert torch.equal(got[k], P[k]), k
+            continue
+        g = 0.5 * (g0[k] + g1[k])                                   # rank average == gradient of the global batch mean
+        m = 0.1 * g; v = 0.001 * g * g
+        ref = P[k] - (1e-3 / 0.1) * m / (v.sqrt() / np.sqrt(0.001) + 1e-8)
+        assert torch.allclose(got[k], ref, rtol=0, atol=2e-6), k
+
+
 def test_shard_range_and_errors():
     import ssie
     ssie.load()

@@ -48,6 +48,32 @@ def test_load_hsi_double_normalisation_and_roundtrip(pkg, tmp_path):
     assert y.shape == cube.shape and abs(y.max() - 1.0) < 1e-6
 
 
+def test_load_hsi_matches_reference_fixtures(pkg, golden_dir, tmp_path):
+    """N2 pinned: `hsi_raw.mat` was written by the reference's utils.save_hsi and `io.npz` holds the reference's
+    utils.load_hsi outputs for it in every mode (tests/golden/make_golden.py, utils.py:36-109,171-178) - bit-exact."""
+    import scipy.io as sio
+    harness, _ = pkg
+    g = np.load(os.path.join(golden_dir, "io.npz"))
+    raw_path = os.path.join(golden_dir, "hsi_raw.mat")
+    calls = {"none": (), "self": ("data", "self"), "global_238_4095": ("data", "global_normalization", 4095.0, 238.0),
+             "global_none_4095": ("data", "global_normalization", 4095.0, None),
+             "per_channel_normalization": ("data", "per_channel_normalization"),
+             "per_channel_standardization": ("data", "per_channel_standardization")}
+    for key, a in calls.items():
+        got = harness.load_hsi(raw_path, *a)
+        assert got.dtype == np.float32 and got.shape == g[key].shape, key
+        assert np.array_equal(got, g[key]), (key, np.abs(got - g[key]).max())
+    assert (g["global_238_4095"] == 0).sum() > 0 and g["global_238_4095"].max() == 1.0       # clamp + second normalisation present
+    with pytest.raises(NotImplementedError):
+        harness.load_hsi(raw_path, "data", "nope")
+    # writer: same file content as the reference's writer produced (key 'data', postfix before the extension)
+    p = str(tmp_path / "w.mat")
+    harness.save_hsi(p, g["raw"])
+    assert np.array_equal(sio.loadmat(p)["data"], sio.loadmat(raw_path)["data"])
+    harness.save_hsi(p, g["raw"][:2, :2], postfix="_R_low")
+    assert os.path.exists(str(tmp_path / "w_R_low.mat"))
+
+
 def test_crop_draw_order_matches_reference_loop(pkg):
     harness, _ = pkg
     shapes = [(96, 80, 5), (70, 90, 5)]
