@@ -144,3 +144,14 @@ __device__ __forceinline__ void ssie_epilogue_ragged(const PT& p, const f32x16& 
         p.out[o] = v;
     }
 }
+
+// Transposed accumulator tiles (bf16 kernels: MFMAs issued as D^T = W x X, lane = output position li of the 2 x 16 M-tile):
+// output-pixel element offset (channel out_coff) and validity of this lane's position; arow / bcol = first tile row / column
+template <typename PT>
+__device__ __forceinline__ size_t ssie_epilogue_pos(const PT& p, int n, int arow, int bcol, int li, bool& ok)
+{
+    const int a = arow + (li >> 4), b = bcol + (li & 15);
+    const int oy = a * p.so + p.py, ox = b * p.so + p.px;
+    ok = a < p.Ho && b < p.Wo && oy < p.Hout && ox < p.Wout;
+    return ((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.out_cstride + p.out_coff;
+}

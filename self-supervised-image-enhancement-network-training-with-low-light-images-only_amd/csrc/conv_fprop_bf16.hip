@@ -15,11 +15,26 @@
 __device__ f32x4 ssie_zero_page_h[4];   // zero-initialised: source of padding slots
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+// Ablation builds only (tools/build_variants.py: -DSSIE_X_NOMFMA / _NODMA / _NOSTORE): one phase of the kernel removed to see
+// what the others cost.  The shipped library defines none of them.
+#ifdef SSIE_X_NOMFMA
+#define MFMA_BF16(a, b, c) ({ asm volatile("" :: "v"(a), "v"(b)); (c); })
+#else
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, (a)), __builtin_bit_cast(bf16x8_t, (b)), (c), 0, 0, 0)
+#endif
 
+#ifdef SSIE_X_NODMA
+#define GLDS16(gptr, lptr) do { asm volatile("" :: "v"(gptr), "v"(lptr)); } while (0)
+#else
 #define GLDS16(gptr, lptr)                                                                             \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),            \
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+#endif
+#ifdef SSIE_X_NOSTORE
+#define SSIE_X_KEEP(okr, val) ((okr) && (val) == 1234.56789f)
+#else
+#define SSIE_X_KEEP(okr, val) (okr)
+#endif
 
 __device__ __forceinline__ float ssie_bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
 
@@ -37,43 +52,74 @@ __device__ __forceinline__ const f32x4* ssie_virtual_addr_h(const SrcSel& s, boo
     return ok ? (const f32x4*)((const unsigned short*)s.ptr + off) : (const f32x4*)ssie_zero_page_h;
 }
 
-#define HOFF(r) ((long)((r) >> 3) * rowstride + (long)(((r) & 3) + 8 * (((r) >> 2) & 1)) * pixstride)
-// one 32 x 32 accumulator tile -> memory; `full` = all 2 x 16 positions lie inside the output
-__device__ __forceinline__ void ssie_epilogue_h(const ConvParams& p, const f32x16& acc, size_t o0, long rowstride, long pixstride, float bv,
-                                                bool full, int arow, int bcol)
+__device__ __forceinline__ uint2 ssie_pack4bf(const f32x4& v) { return make_uint2(ssie_pack2bf(v[0], v[1]), ssie_pack2bf(v[2], v[3])); }
+__device__ __forceinline__ f32x4 ssie_unpack4bf(uint2 u)
 {
-    float v[16];
-    bool ok[16];
+    f32x4 r = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+    return r;
+}
+
+// one 32 x 32 accumulator tile -> memory, TRANSPOSED layout (the MFMAs are issued as D^T = W x X; see ssie_epilogue_t in
+// conv_device.h): lane (li, h) = output position li of the 2 x 16 M-tile, register r = channel 8*(r>>2) + 4h + (r&3).  Four
+// groups of four consecutive channels per lane: bf16 tensors move 8 bytes per group, fp32 outputs 16.
+//   opix = element offset of (this lane's pixel, channel out_coff); c0 = first channel of the N-tile + 4h
+__device__ __forceinline__ void ssie_epilogue_ht(const ConvParams& p, const f32x16& acc, size_t opix, int c0, bool pos_ok)
+{
+    if (!pos_ok) return;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 v[4];
+    bool full[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int a = arow + (r >> 3), b = bcol + (r & 3) + 8 * ((r >> 2) & 1);
-        ok[r] = full || (a < p.Ho && b < p.Wo && a * p.so + p.py < p.Hout && b * p.so + p.px < p.Wout);
-        float t = acc[r] + bv;
-        if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
-        else if (p.act == ACT_SIGMOID) t = 1.f / (1.f + expf(-t));
-        v[r] = t;
+    for (int g = 0; g < 4; ++g) {
+        const int c = c0 + 8 * g;
+        full[g] = c + 4 <= p.Cout;
+        const f32x4 b = (p.bias && full[g]) ? *(const f32x4*)(p.bias + c) : z4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float t = acc[4 * g + j] + b[j];
+            if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
+            else if (p.act == ACT_SIGMOID) t = 1.f / (1.f + expf(-t));
+            v[g][j] = t;
+        }
     }
     if (p.out2) {
-        unsigned short* o2 = (unsigned short*)p.out2 + o0;
+        unsigned short* o2 = (unsigned short*)p.out2 + opix + c0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) if (ok[r]) o2[HOFF(r)] = ssie_f2bf(v[r]);
+        for (int g = 0; g < 4; ++g) if (SSIE_X_KEEP(full[g], v[g][0])) *(uint2*)(o2 + 8 * g) = ssie_pack4bf(v[g]);
     }
     if (p.addsrc) {
-        const unsigned short* ap = (const unsigned short*)p.addsrc + o0;
-        unsigned short a[16];
+        const unsigned short* ap = (const unsigned short*)p.addsrc + opix + c0;
+        uint2 a[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a[r] = ok[r] ? ap[HOFF(r)] : (unsigned short)0;
+        for (int g = 0; g < 4; ++g) a[g] = full[g] ? *(const uint2*)(ap + 8 * g) : make_uint2(0u, 0u);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] += ssie_bf2f(a[r]);
+        for (int g = 0; g < 4; ++g) v[g] += ssie_unpack4bf(a[g]);
     }
     if (p.out_bf16) {
-        unsigned short* ob = (unsigned short*)p.out + o0;
+        unsigned short* ob = (unsigned short*)p.out + opix + c0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) if (ok[r]) ob[HOFF(r)] = ssie_f2bf(v[r]);
+        for (int g = 0; g < 4; ++g) if (SSIE_X_KEEP(full[g], v[g][0])) *(uint2*)(ob + 8 * g) = ssie_pack4bf(v[g]);
     } else {
-        float* ob = p.out + o0;
+        float* ob = p.out + opix + c0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) if (ok[r]) ob[HOFF(r)] = v[r];
+        for (int g = 0; g < 4; ++g) if (SSIE_X_KEEP(full[g], v[g][0])) *(f32x4*)(ob + 8 * g) = v[g];
+    }
+    // the group that straddles Cout (Cout % 4 != 0, e.g. the 1-channel final_conv), element by element
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int c = c0 + 8 * g;
+        if (full[g] || c >= p.Cout) continue;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (c + j >= p.Cout) break;
+            const size_t o = opix + c + j;
+            float t = acc[4 * g + j] + (p.bias ? p.bias[c + j] : 0.f);
+            if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
+            else if (p.act == ACT_SIGMOID) t = 1.f / (1.f + expf(-t));
+            if (p.out2) ((unsigned short*)p.out2)[o] = ssie_f2bf(t);
+            if (p.addsrc) t += ssie_bf2f(((const unsigned short*)p.addsrc)[o]);
+            if (p.out_bf16) ((unsigned short*)p.out)[o] = ssie_f2bf(t); else p.out[o] = t;
+        }
     }
 }
 
@@ -207,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16_kernel(const ConvParam
                         af[m] = As[hp * 4 + ((sc * 2 + h) ^ ssie_swz(hp))];
                     }
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) acc[m] = MFMA_BF16(af[m], bf, acc[m]);
+                    for (int m = 0; m < MT; ++m) acc[m] = MFMA_BF16(bf, af[m], acc[m]);
                 }
             }
             if (tid == 0 && step == 0 && nsteps > 1 && p.tile_counter)
@@ -215,20 +261,13 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16_kernel(const ConvParam
             chunk = nchunk; g = ng; a_cur = a_nxt;
         }
 
-        const int co = co0 + wn * 32 + li;
-        if (co < p.Cout) {
-            const float bv = p.bias ? p.bias[co] : 0.f;
-            const long rowstride = (long)p.so * p.Wout * p.out_cstride;
-            const long pixstride = (long)p.so * p.out_cstride;
-            const bool full = a0 + TH <= p.Ho && b0 + SSIE_TW <= p.Wo &&
-                              (a0 + TH - 1) * p.so + p.py < p.Hout && (b0 + SSIE_TW - 1) * p.so + p.px < p.Wout;
+        // epilogue: D^T = W x X above, so lane li = position of the 2 x 16 M-tile, registers = channels (ssie_epilogue_ht)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int mt = wm * MT + m;
-                const int arow = a0 + 2 * mt, bcol = b0 + 4 * h;
-                const size_t o0 = ((size_t)(n * p.Hout + arow * p.so + p.py) * p.Wout + bcol * p.so + p.px) * p.out_cstride + p.out_coff + co;
-                ssie_epilogue_h(p, acc[m], o0, rowstride, pixstride, bv, full, arow, bcol);
-            }
+        for (int m = 0; m < MT; ++m) {
+            const int mt = wm * MT + m;
+            bool ok;
+            const size_t opix = ssie_epilogue_pos(p, n, a0 + 2 * mt, b0, li, ok);
+            ssie_epilogue_ht(p, acc[m], opix, co0 + wn * 32 + 4 * h, ok);
         }
         n = nn; a0 = na0; b0 = nb0; co0 = nco0; tile = ntile;
     }
@@ -387,7 +426,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16w_kernel(const ConvPara
             }
 #define W_MFMA(BF, AF)                                                                                    \
             _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_)                                             \
-            _Pragma("unroll") for (int c_ = 0; c_ < NT; ++c_) acc[m_][c_] = MFMA_BF16(AF[m_], BF[c_], acc[m_][c_]);
+            _Pragma("unroll") for (int c_ = 0; c_ < NT; ++c_) acc[m_][c_] = MFMA_BF16(BF[c_], AF[m_], acc[m_][c_]);
             {
                 f32x4 bX[NT], bY[NT], aX[MT], aY[MT];
                 W_LD(bX, aX, 0, 0)
@@ -409,24 +448,14 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16w_kernel(const ConvPara
             chunk = nchunk; g = ng; a_cur = a_nxt;
         }
 
-        // epilogue: wave w holds tile rows 2w, 2w+1; M-tile m = columns 16m .. 16m+15, N-tile c = channels 32c .. 32c+31
-        {
-            const long rowstride = (long)p.so * p.Wout * p.out_cstride;
-            const long pixstride = (long)p.so * p.out_cstride;
-            const bool full = a0 + TH <= p.Ho && b0 + TWW <= p.Wo &&
-                              (a0 + TH - 1) * p.so + p.py < p.Hout && (b0 + TWW - 1) * p.so + p.px < p.Wout;
+        // epilogue: wave w holds tile rows 2w, 2w+1; M-tile m = columns 16m .. 16m+15, N-tile c = channels 32c .. 32c+31;
+        // D^T = W x X above, so lane li = position, registers = channels (ssie_epilogue_ht)
 #pragma unroll
-            for (int c = 0; c < NT; ++c) {
-                const int co = co0 + c * 32 + li;
-                if (co >= p.Cout) continue;
-                const float bv = p.bias ? p.bias[co] : 0.f;
+        for (int m = 0; m < MT; ++m) {
+            bool ok;
+            const size_t opix = ssie_epilogue_pos(p, n, a0 + 2 * wave, b0 + 16 * m, li, ok);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const int arow = a0 + 2 * wave, bcol = b0 + 16 * m + 4 * h;
-                    const size_t o0 = ((size_t)(n * p.Hout + arow * p.so + p.py) * p.Wout + bcol * p.so + p.px) * p.out_cstride + p.out_coff + co;
-                    ssie_epilogue_h(p, acc[m][c], o0, rowstride, pixstride, bv, full, arow, bcol);
-                }
-            }
+            for (int c = 0; c < NT; ++c) ssie_epilogue_ht(p, acc[m][c], opix, co0 + c * 32 + 4 * h, ok);
         }
         n = nn; a0 = na0; b0 = nb0; co0 = nco0; tile = ntile;
     }

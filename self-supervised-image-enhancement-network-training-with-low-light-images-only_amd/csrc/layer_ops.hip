@@ -97,6 +97,9 @@ int ssie_make_conv(ConvParams& p, const SrcDesc* srcs, int nsrc, int N, int Hv, 
         if (((uintptr_t)srcs[s].ptr) % 16) return SSIE_E_SHAPE;
         cin += srcs[s].C;
     }
+    // the epilogue moves 16 bytes along the channel axis per access (conv_device.h, ssie_epilogue_t)
+    if (out_cstride % 4 || out_coff % 4 || ((uintptr_t)out | (uintptr_t)e.bias | (uintptr_t)e.addsrc | (uintptr_t)e.out2 | (uintptr_t)e.mask_y) % 16)
+        return SSIE_E_SHAPE;
     p.nsrc = nsrc; p.N = N; p.Hv = Hv; p.Wv = Wv; p.Cin = cin; p.nchunks = ssie_ceil_div(cin, SSIE_CK);
     p.Ho = Ho; p.Wo = Wo; p.si = si; p.ntaps = t.n;
     int mny, mxy, mnx, mxx; tap_extent(t, mny, mxy, mnx, mxx);

@@ -53,3 +53,9 @@ size_t ssie_fft_workspace_floats(int N, int B, int H, int W);
 void ssie_fft_set_logs(FftParams& p);        // fills logH / logW for the path ssie_fft_supported(H, W) selects
 int ssie_launch_fft_loss(const FftParams& p, hipStream_t st);
 void ssie_fourier_mask_host(int H, int W, float cutoff, uint8_t* out);
+
+// fused inference tail (tail_kernels.hip): feature_fusion + final_conv + S = R*(I_delta + I_low) in one launch
+int ssie_tail_supported(int H, int W, int H2, int W2, int H4, int W4);
+int ssie_launch_tail_weights(const float* wf, const float* bf, const float* wl, const float* bl, float* out, hipStream_t st);
+int ssie_launch_tail(const void* d1, const void* d2, const void* d3, int bf16_in, int N, int H, int W, int H2, int W2, int H4, int W4,
+                     const float* wc, const float* RL, int rl_cs, float* D, int d_cs, float* S, int s_cs, int B, hipStream_t st);

@@ -139,6 +139,201 @@ __global__ __launch_bounds__(256) void loss_direct_kernel(const LossParams p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tiled variant (the one the plan runs for up to 252 bands): one workgroup per TH x TW pixel tile.
+//   * the tile of R|I (pass 1) and of R_enh (pass 2) is staged ONCE, with a one-pixel halo, into LDS by 16-byte loads;
+//     x and S (no spatial neighbours needed) go straight to registers, issued BEFORE the staging loads so that every byte
+//     the tile needs is in flight together
+//   * LPP lanes share a pixel, each owning four consecutive bands (one float4): all HBM accesses are 16 bytes per lane and
+//     contiguous over the pixel's band vector; the band reductions are LPP-lane butterflies
+//   * one pass: the per-band edge terms (|dR|, exp(-a2 |dR|), sg(dR)) of the four edges are computed once, kept in registers
+//     across the band reduction and reused for the cotangents (the half-wave kernel above evaluates each twice)
+// Same arithmetic per element as loss_direct_kernel (single subtractions for every sg() argument), so the results agree to
+// the rounding of the reductions' summation order.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
+
+template <int LPP>
+__device__ __forceinline__ float grp_sum(float v)      // sum over the LPP lanes that share a pixel
+{
+#pragma unroll
+    for (int o = LPP >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int LPP>
+__global__ __launch_bounds__(256) void loss_tile_kernel(const LossParams p, int TH, int TW, int tiles_y, int tiles_x)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_l[];
+    constexpr int SLOTS = 256 / LPP;                   // pixels per pass
+    constexpr int MAXPASS = 4;
+    const int B = p.B, H = p.H, W = p.W;
+    const int nq = p.rl_cs >> 2, nqx = p.x_cs >> 2;    // float4s per pixel of RL / E and of x / S
+    const int PW = TW + 2, PH = TH + 2, pxh = PH * PW;
+    float* RLt = smem_l;                               // [PH][PW][rl_cs]
+    float* Et = RLt + (size_t)pxh * p.rl_cs;           // [PH][PW][rl_cs]
+    float* Dt = Et + (size_t)pxh * p.rl_cs;            // [PH][PW]
+    const int tid = threadIdx.x, sub = tid % LPP, grp = tid / LPP;
+    const int c0 = sub * 4;
+    const bool lane_rl = sub < nq, lane_x = sub < nqx;
+    float cm[4];                                       // 1 for real bands, 0 for the I / padding channels of this lane's float4
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cm[k] = (c0 + k < B) ? 1.f : 0.f;
+    const float invC = 1.f / (float)B;
+    const float kil_x = p.c_il * p.a1 * invC * p.inv_nIx, kil_y = p.c_il * p.a1 * invC * p.inv_nIy;
+    const float kid_x = p.c_id * p.a2 * p.inv_nRx, kid_y = p.c_id * p.a2 * p.inv_nRy;
+    float acc_rec = 0.f, acc_rf = 0.f, acc_il = 0.f, acc_id = 0.f, acc_sp = 0.f;
+    const int per_img = tiles_y * tiles_x, ntiles = p.N * per_img, npass = (TH * TW + SLOTS - 1) / SLOTS;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int n = tile / per_img, tr = tile - n * per_img, ty = tr / tiles_x, tx = tr - ty * tiles_x;
+        const int h0 = ty * TH, w0 = tx * TW;
+        const long img = (long)n * H * W;
+        // ---- x and S of this lane's pixels, all passes, straight to registers ----
+        f32x4 xv[MAXPASS], sv[MAXPASS];
+#pragma unroll
+        for (int ps = 0; ps < MAXPASS; ++ps) {
+            const int idx = ps * SLOTS + grp, ph = idx / TW, pw = idx - ph * TW;
+            const bool ok = ps < npass && idx < TH * TW && h0 + ph < H && w0 + pw < W && lane_x;
+            const long pix = img + (long)(h0 + ph) * W + (w0 + pw);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            xv[ps] = ok ? ld4(p.x + pix * p.x_cs + c0) : z;
+            sv[ps] = ok ? ld4(p.S + pix * p.s_cs + c0) : z;
+        }
+        __syncthreads();                               // the previous tile's LDS reads are done
+        // ---- stage R|I, R_enh (halo of one pixel; zeros outside the image) and I_delta ----
+        for (int i = tid; i < pxh * nq; i += 256) {
+            const int px = i / nq, q = i - px * nq, py = px / PW, pxx = px - py * PW;
+            const int hh = h0 - 1 + py, ww = w0 - 1 + pxx;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+            if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
+                const long pix = img + (long)hh * W + ww;
+                a = ld4(p.RL + pix * p.rl_cs + 4 * q); b = ld4(p.E + pix * p.e_cs + 4 * q);
+            }
+            *(f32x4*)(RLt + (size_t)px * p.rl_cs + 4 * q) = a;
+            *(f32x4*)(Et + (size_t)px * p.rl_cs + 4 * q) = b;
+        }
+        for (int i = tid; i < pxh; i += 256) {
+            const int py = i / PW, pxx = i - py * PW, hh = h0 - 1 + py, ww = w0 - 1 + pxx;
+            Dt[i] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? p.D[(img + (long)hh * W + ww) * p.d_cs] : 0.f;
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int ps = 0; ps < MAXPASS; ++ps) {
+            if (ps >= npass) break;
+            const int idx = ps * SLOTS + grp, ph = idx / TW, pw = idx - ph * TW;
+            const int h = h0 + ph, w = w0 + pw;
+            const bool live = idx < TH * TW && h < H && w < W;          // uniform over the LPP lanes of a pixel
+            const int li = live ? (ph + 1) * PW + (pw + 1) : PW + 1;    // dead slots read a valid LDS address and store nothing
+            const bool hasR = live && w + 1 < W, hasL = live && w > 0, hasD = live && h + 1 < H, hasU = live && h > 0;
+            const float fR = hasR ? 1.f : 0.f, fL = hasL ? 1.f : 0.f, fD = hasD ? 1.f : 0.f, fU = hasU ? 1.f : 0.f;
+            const int nb[4] = {li + 1, li - 1, li + PW, li - PW};         // R, L, D, U
+            const float sgnd[4] = {1.f, -1.f, 1.f, -1.f};               // edge difference = sgnd * (neighbour - own)
+            const float hasf[4] = {fR, fL, fD, fU};
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 r0 = lane_rl ? *(const f32x4*)(RLt + (size_t)li * p.rl_cs + c0) : z4;
+            const f32x4 e0 = lane_rl ? *(const f32x4*)(Et + (size_t)li * p.rl_cs + c0) : z4;
+            const float I0 = RLt[(size_t)li * p.rl_cs + B], D0 = Dt[li];
+            f32x4 dRv[4], exv[4], ddv[4];
+            float a_sum[4], e_sum[4], u[4], v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 rn = lane_rl ? *(const f32x4*)(RLt + (size_t)nb[k] * p.rl_cs + c0) : z4;
+                const f32x4 en = lane_rl ? *(const f32x4*)(Et + (size_t)nb[k] * p.rl_cs + c0) : z4;
+                u[k] = sgnd[k] * (RLt[(size_t)nb[k] * p.rl_cs + B] - I0);
+                v[k] = sgnd[k] * (Dt[nb[k]] - D0);
+                float as = 0.f, es = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = sgnd[k] * (rn[j] - r0[j]);                 // one subtraction, like the reference's R[1:] - R[:-1]
+                    const float ex = expf(-p.a2 * fabsf(d));
+                    dRv[k][j] = d; exv[k][j] = ex;
+                    ddv[k][j] = sgnd[k] * ((rn[j] - en[j]) - (r0[j] - e0[j]));
+                    as += cm[j] * fabsf(d); es += cm[j] * ex;
+                }
+                a_sum[k] = grp_sum<LPP>(as) * hasf[k]; e_sum[k] = grp_sum<LPP>(es) * hasf[k];
+            }
+            const f32x4 xr = xv[ps];
+            float srs = 0.f;
+            float srec[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t = r0[j] * I0 - xr[j];
+                srec[j] = cm[j] * sgnf(t);
+                srs += srec[j] * r0[j];
+                acc_rec += live ? cm[j] * fabsf(t) * p.inv_n0 : 0.f;
+            }
+            srs = grp_sum<LPP>(srs);
+            float wgt[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wgt[k] = expf(-p.a1 * a_sum[k] * invC);
+            // ---- per-pixel cotangents (I_low, I_delta): identical on all LPP lanes; the lane owning channel B stores gI ----
+            float gI = p.c_rec * p.inv_n0 * srs, gDv = 0.f;
+            {
+                const float nIx = p.inv_nIx, nIy = p.inv_nIy, nRx = p.inv_nRx, nRy = p.inv_nRy;
+                gI += -fR * p.c_il * wgt[0] * sgnf(u[0]) * nIx + fL * p.c_il * wgt[1] * sgnf(u[1]) * nIx
+                      - fD * p.c_il * wgt[2] * sgnf(u[2]) * nIy + fU * p.c_il * wgt[3] * sgnf(u[3]) * nIy;
+                gDv += -fR * p.c_id * sgnf(v[0]) * e_sum[0] * nRx + fL * p.c_id * sgnf(v[1]) * e_sum[1] * nRx
+                       - fD * p.c_id * sgnf(v[2]) * e_sum[2] * nRy + fU * p.c_id * sgnf(v[3]) * e_sum[3] * nRy;
+                if (sub == 0) acc_il += fR * wgt[0] * fabsf(u[0]) * nIx + fD * wgt[2] * fabsf(u[2]) * nIy;
+            }
+            // ---- per-band cotangents ----
+            const float kil[4] = {kil_x, kil_x, kil_y, kil_y}, kid[4] = {kid_x, kid_x, kid_y, kid_y};
+            const float nR[4] = {p.inv_nRx, p.inv_nRx, p.inv_nRy, p.inv_nRy};
+            const float esg[4] = {1.f, -1.f, 1.f, -1.f};                    // own-end sign of an edge's flux
+            f32x4 gR, g8, gs;
+            const f32x4 sr = sv[ps];
+            // band neighbours of S across the float4 boundary come from the adjacent lanes of the pixel group
+            const float s_prev = __shfl_up(sr[3], 1), s_next = __shfl_down(sr[0], 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = c0 + j;
+                const float d0 = r0[j] - e0[j];
+                float g = p.c_rec * p.inv_n0 * srec[j] * I0;
+                float gdel = sgnf(d0) * p.inv_n0;
+                acc_rf += live ? cm[j] * fabsf(d0) * p.inv_n0 : 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float d = dRv[k][j], ex = exv[k][j], dd = ddv[k][j];
+                    g += esg[k] * hasf[k] * sgnf(d) * (kil[k] * wgt[k] * fabsf(u[k]) + kid[k] * fabsf(v[k]) * ex);
+                    gdel -= esg[k] * hasf[k] * 0.5f * sgnf(dd) * nR[k];
+                    if (k == 0 || k == 2) {                                  // each edge's loss is counted at its left / upper end
+                        acc_rf += cm[j] * hasf[k] * 0.5f * fabsf(dd) * nR[k];
+                        acc_id += cm[j] * hasf[k] * fabsf(v[k]) * ex * nR[k];
+                    }
+                }
+                g += p.c_rf * gdel;
+                const float ge = p.ge_raw ? -p.c_rf * gdel : -p.c_rf * gdel * e0[j] * (1.f - e0[j]);
+                gR[j] = c < B ? g : (c == B ? gI : 0.f);
+                g8[j] = c < B ? ge : 0.f;
+                // spectral TV along the band axis (model.py:475-481)
+                const float s0 = sr[j];
+                const float sm = j > 0 ? sr[j - 1] : s_prev, sp = j < 3 ? sr[j + 1] : s_next;
+                float gsv = 0.f;
+                if (c > 0 && c < B) gsv += sgnf(s0 - sm);
+                if (c + 1 < B) { const float t = sp - s0; gsv -= sgnf(t); acc_sp += live ? fabsf(t) * p.inv_nsp : 0.f; }
+                gs[j] = p.c_sp * p.inv_nsp * gsv;
+            }
+            if (live) {
+                const long pix = img + (long)h * W + w;
+                if (lane_rl) { *(f32x4*)(p.gRL + pix * p.rl_cs + c0) = gR; *(f32x4*)(p.G8b + pix * p.e_cs + c0) = g8; }
+                if (lane_x) *(f32x4*)(p.gS + pix * p.s_cs + c0) = gs;
+                if (sub == 0) p.gD[pix * p.d_cs] = gDv;
+            }
+        }
+    }
+    // block reduction of the five loss sums (every block writes its slot, also when it had no tile)
+    __shared__ float red[5][4];
+    float s5[5] = {acc_rec, acc_rf, acc_il, acc_id, acc_sp};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { float t = s5[k]; for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o); s5[k] = t; }
+    __syncthreads();
+    if ((tid & 63) == 0) for (int k = 0; k < 5; ++k) red[k][tid >> 6] = s5[k];
+    __syncthreads();
+    if (tid < 5) p.partials[(size_t)blockIdx.x * 8 + tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+}
+
 // terms[0..5] = (rec, rf, il, id, fourier, sp); out[0] = total, out[1..6] = terms in LOSS order.
 // One 256-thread block; fixed-order tree reduction in double => deterministic.
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ partials, int nblk,
@@ -279,9 +474,40 @@ static inline unsigned grid_for(long total, int per_block, int cap = 4096)
     return (unsigned)b;
 }
 
+static void allow_lds(const void* fn, size_t bytes)
+{
+    if (bytes <= 64 * 1024) return;
+    static const void* seen[8][16];                   // hipFuncSetAttribute is per device
+    int dev = 0; hipGetDevice(&dev);
+    if (dev >= 0 && dev < 16)
+        for (int i = 0; i < 8; ++i) {
+            if (seen[i][dev] == fn) return;
+            if (!seen[i][dev]) { seen[i][dev] = fn; break; }
+        }
+    hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+int ssie_loss_force_generic = 0;      // include/ssie_debug.h: 1 = always the half-wave-per-pixel kernel (tests run both)
+
 int ssie_launch_loss_direct(const LossParams& p, int nblk, hipStream_t st)
 {
-    hipLaunchKernelGGL(loss_direct_kernel, dim3(nblk), dim3(256), 0, st, p);
+    const int nq = p.rl_cs / 4;
+    const bool aligned = (((uintptr_t)p.x | (uintptr_t)p.RL | (uintptr_t)p.S | (uintptr_t)p.E | (uintptr_t)p.gRL | (uintptr_t)p.gS |
+                           (uintptr_t)p.G8b) & 15) == 0;
+    const bool tiled = !ssie_loss_force_generic && aligned && p.rl_cs == p.e_cs && p.x_cs == p.s_cs && p.rl_cs % 4 == 0 &&
+                       p.x_cs % 4 == 0 && p.x_cs <= p.rl_cs && p.B < p.rl_cs && nq <= 64;
+    if (!tiled) {
+        hipLaunchKernelGGL(loss_direct_kernel, dim3(nblk), dim3(256), 0, st, p);
+        return hipGetLastError() == hipSuccess ? 0 : 41;
+    }
+    const int lpp = nq <= 8 ? 8 : nq <= 16 ? 16 : nq <= 32 ? 32 : 64;
+    const int TW = lpp <= 16 ? 16 : 8, TH = 4 * (256 / lpp) / TW;          // 4 passes of 256 / LPP pixels
+    const int tiles_y = ssie_ceil_div(p.H, TH), tiles_x = ssie_ceil_div(p.W, TW);
+    const size_t lds = (size_t)(TH + 2) * (TW + 2) * (2 * p.rl_cs + 1) * 4;
+#define LAUNCH_TILE(L) do { allow_lds((const void*)loss_tile_kernel<L>, lds);                                               \
+        hipLaunchKernelGGL(loss_tile_kernel<L>, dim3(nblk), dim3(256), lds, st, p, TH, TW, tiles_y, tiles_x); } while (0)
+    if (lpp == 8) LAUNCH_TILE(8); else if (lpp == 16) LAUNCH_TILE(16); else if (lpp == 32) LAUNCH_TILE(32); else LAUNCH_TILE(64);
+#undef LAUNCH_TILE
     return hipGetLastError() == hipSuccess ? 0 : 41;
 }
 int ssie_launch_loss_finalize(const float* partials, int nblk, const float* fpartials, int nfblk,

@@ -46,7 +46,7 @@ struct Plan {
     std::map<std::string, BufInfo> bufs;
     size_t ws_floats = 0;
     size_t slab_off = 0, slab_off2 = 0, slab_cap = 0, partial_off = 0, packdesc_off = 0, mask_off = 0, scal_off = 0;
-    size_t lpart_off = 0, fpart_off = 0, counter_off = 0, fftws_off = 0;
+    size_t lpart_off = 0, fpart_off = 0, counter_off = 0, fftws_off = 0, tailw_off = 0;
     int counter_cursor = 0;
     int loss_blocks = 0, fft_blocks = 0;
     float coefs[8];
@@ -56,8 +56,10 @@ struct Plan {
     size_t pack_cursor = 0, pack_floats_total = 0, pack_off = 0;
     std::vector<Fn> fwd, pass2, lossbwd;
     std::vector<Fn> fwd16;       // enhance-only forward with bf16 storage / bf16 MFMA (ssie_plan_enhance_fwd_bf16)
+    std::vector<Fn> fwdi;        // enhance-only forward in fp32: `fwd` with its last three launches replaced by the fused tail
     size_t npacks_train = 0;     // packs[0 .. npacks_train) belong to the fp32 lists, the rest to fwd16
     bool bound = false;
+    bool fused_tail = true;      // captured at creation (ssie_debug_set_fused_tail): the dry build and the bound build must agree
     // the slab reductions (HBM-bound) run on a side stream underneath the next MFMA-bound launches; wgrad launches
     // alternate between two slab areas so that a reduction only has to finish before the wgrad AFTER the next one
     int slab_seq = 0;
@@ -168,6 +170,7 @@ void build_buffers(Plan& pl)
     pl.scal_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 16, 64);
     pl.fftws_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + ssie_fft_workspace_floats(N, B, H, W), 64);   // patches above 128 x 128 only
     pl.mask_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + ((size_t)H * W + 3) / 4, 64);
+    pl.tailw_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 3 * 9 * 64 + 16, 64);     // composite weights of the fused tail
     pl.counter_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 1024, 64);      // tile-queue counters, one per conv launch
     pl.packdesc_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 384 * sizeof(PackDesc) / 4, 64);
     pl.pack_off = pl.ws_floats;     // packed weights grow from here at bind time (size known after a dry build)
@@ -396,7 +399,25 @@ int build_decomposition_fwd(Builder& b, std::vector<Fn>& ops, const char* xin, i
     return 0;
 }
 
-int build_illum_fwd(Builder& b, std::vector<Fn>& ops)
+// fused inference tail (tail_kernels.hip) in place of feature_fusion + final_conv + compose
+void push_tail(Builder& b, std::vector<Fn>& ops)
+{
+    Plan& pl = b.pl;
+    if (b.dry) return;
+    const std::string i = "illum_adjust_net.";
+    const LayerP Lu = layer(pl, i + "feature_fusion.0"), Lf = layer(pl, i + "final_conv");
+    const float* wf = pl.P + Lu.w; const float* bf = pl.P + Lu.b; const float* wl = pl.P + Lf.w; const float* bl = pl.P + Lf.b;
+    float* wc = pl.ws + pl.tailw_off;
+    ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_tail_weights(wf, bf, wl, bl, wc, st); }, K_ELEMENTWISE, 0.0, "tail weights"));
+    const void* d1 = pl.buf("d1"); const void* d2 = pl.buf("d2"); const void* d3 = pl.buf("d3");
+    const float* RL = pl.buf("RL_1"); float* D = pl.buf("D"); float* S = pl.buf("S");
+    const int h16 = b.h16, N = pl.N, H = pl.H, W = pl.W, H2 = pl.H2, W2 = pl.W2, H4 = pl.H4, W4 = pl.W4, rl = pl.CRL, cx = pl.CX, B = pl.B;
+    const double fl = 2.0 * N * H * W * (192.0 * 64 + 64.0 * 9);      // algorithmic FLOPs of the two layers it replaces
+    ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_tail(d1, d2, d3, h16, N, H, W, H2, W2, H4, W4, wc, RL, rl, D, 4, S, cx, B, st); },
+                     K_ELEMENTWISE, fl, "fused tail: fusion 1x1 + final 3x3 + compose"));
+}
+
+int build_illum_fwd(Builder& b, std::vector<Fn>& ops, bool fused_tail = false)
 {
     Plan& pl = b.pl;
     const int H = pl.H, W = pl.W, H2 = pl.H2, W2 = pl.W2, H4 = pl.H4, W4 = pl.W4, H8 = pl.H8, W8 = pl.W8;
@@ -423,6 +444,7 @@ int build_illum_fwd(Builder& b, std::vector<Fn>& ops)
     CK(b.conv(ops, layer(pl, i + "deconv1.0"), {b.src("t3", 64, H4, W4)}, H4, W4, 1, "d1", ACT_RELU, "a2", "u1"));
     CK(b.conv(ops, layer(pl, i + "deconv2.0"), {b.src("d1", 64, H2, W2)}, H2, W2, 1, "d2", ACT_RELU, "a1", "u2"));
     CK(b.conv(ops, layer(pl, i + "deconv3.0"), {b.src("d2", 64, H, W)}, H, W, 1, "d3", ACT_RELU, "a0", "u3"));
+    if (fused_tail) { push_tail(b, ops); return 0; }
     CK(b.conv(ops, layer(pl, i + "feature_fusion.0"), {b.src("d1", 64, H, W), b.src("d2", 64, H, W), b.src("d3", 64, H, W)}, H, W, 1, "f", ACT_NONE));
     CK(b.conv(ops, layer(pl, i + "final_conv"), {b.src("f", 64, H, W)}, H, W, 1, "D", ACT_NONE));
     if (!b.dry) {
@@ -612,6 +634,7 @@ int build_all(Plan& pl, bool dry)
     // bf16 inference list (its packs follow the fp32 ones)
     pl.npacks_train = pl.packs.size();
     pl.fwd16.clear();
+    const bool tail_ok = pl.fused_tail && ssie_tail_supported(pl.H, pl.W, pl.H2, pl.W2, pl.H4, pl.W4) != 0;
     if (pl.CX % 8 == 0 && pl.CRL % 8 == 0) {      // bf16 pixels are read in 16-byte (8-channel) slots; e.g. B = 31, 63, 127
         b.h16 = true;
         if (!b.dry) {
@@ -619,8 +642,15 @@ int build_all(Plan& pl, bool dry)
             pl.fwd16.push_back(Fn([=](hipStream_t st) { return ssie_launch_to_bf16(xf, xh, ne, st); }));
         }
         CK(build_decomposition_fwd(b, pl.fwd16, "x", 1));
-        CK(build_illum_fwd(b, pl.fwd16));
+        CK(build_illum_fwd(b, pl.fwd16, tail_ok));
         b.h16 = false;
+    }
+    // fp32 enhance-only list: the training forward minus its last three launches (feature_fusion, final_conv, compose) plus
+    // the fused tail; training keeps `fwd` (the two layers' weight gradients need the tensor f)
+    pl.fwdi.clear();
+    if (!dry && tail_ok && pl.fwd.size() > 3) {
+        pl.fwdi.assign(pl.fwd.begin(), pl.fwd.end() - 3);
+        push_tail(b, pl.fwdi);
     }
     pl.pack_floats_total = pl.pack_cursor;
     return 0;
@@ -632,6 +662,7 @@ int run_ops(std::vector<Fn>& ops, hipStream_t st)
     return 0;
 }
 
+int g_fused_tail = 1;   // ssie_debug_set_fused_tail: 0 = inference runs feature_fusion / final_conv / compose as separate launches
 int g_overlap = 1;      // ssie_debug_set_overlap: 0 = everything in launch order on the caller's stream
 
 // backward schedule with the slab reductions on the side stream:
@@ -676,7 +707,7 @@ extern "C" void* ssie_plan_create(int N, int bands, int H, int W, const float* c
 {
     if (N < 1 || bands < 2 || H < 8 || W < 8 || (H & 1) || (W & 1)) return nullptr;   // model.py:59 needs even H, W
     Plan* pl = new Plan();
-    pl->N = N; pl->B = bands; pl->H = H; pl->W = W;
+    pl->N = N; pl->B = bands; pl->H = H; pl->W = W; pl->fused_tail = g_fused_tail != 0;
     pl->CX = ssie_round_up(bands, 4); pl->CRL = ssie_round_up(bands + 1, 4);
     pl->H2 = (H + 1) / 2; pl->W2 = (W + 1) / 2; pl->H4 = (pl->H2 + 1) / 2; pl->W4 = (pl->W2 + 1) / 2;
     pl->H8 = (pl->H4 + 1) / 2; pl->W8 = (pl->W4 + 1) / 2;
@@ -693,6 +724,7 @@ extern "C" void* ssie_plan_create(int N, int bands, int H, int W, const float* c
 }
 
 extern "C" void ssie_debug_set_overlap(int on) { g_overlap = on; }
+extern "C" void ssie_debug_set_fused_tail(int on) { g_fused_tail = on; }     // takes effect for plans bound afterwards
 extern "C" void ssie_plan_destroy(void* h) { delete (Plan*)h; }
 extern "C" size_t ssie_plan_workspace_bytes(void* h) { return h ? ((Plan*)h)->ws_floats * 4 : 0; }
 extern "C" size_t ssie_plan_param_floats(void* h) { return h ? ((Plan*)h)->nparam_floats : 0; }
@@ -780,7 +812,7 @@ extern "C" int ssie_plan_enhance_fwd(void* h, const float* x, const long* stride
     hipStream_t st = (hipStream_t)stream;
     CK(pack_all(pl, st));
     CK(ingest(pl, x, strides4, st));
-    return run_ops(pl->fwd, st);
+    return run_ops(pl->fwdi.empty() ? pl->fwd : pl->fwdi, st);
 }
 
 // enhance-only forward with bf16 activations / weights and bf16 MFMA (fp32 accumulate, fp32 bias / activation / attention);
@@ -908,7 +940,7 @@ extern "C" int ssie_plan_profile_list(void* h, const float* x, const long* strid
     Plan* pl = (Plan*)h;
     if (!pl || !pl->bound || !x || !strides4) return -SSIE_E_ARG;
     hipStream_t st = (hipStream_t)stream;
-    std::vector<Fn>& seq = which == 1 ? pl->fwd16 : pl->fwd;
+    std::vector<Fn>& seq = which == 1 ? pl->fwd16 : (pl->fwdi.empty() ? pl->fwd : pl->fwdi);
     if ((int)seq.size() > cap) return -SSIE_E_WORKSPACE;
     std::vector<hipEvent_t> ev(seq.size() + 1);
     for (auto& e : ev) hipEventCreate(&e);

@@ -1,0 +1,189 @@
+// Fused tail of the enhance-only forward (inference entry, /root/reference/model.py:168-175 and :233):
+//   gather = cat[up(d1), up(d2), d3] -> feature_fusion (1x1, 192 -> 64, no activation) -> final_conv (3x3, 64 -> 1) -> I_delta
+//   S = R_low * I_delta + R_low * I_low
+// Both convolutions are linear with nothing in between, so I_delta is ONE 3x3 convolution of the 192-channel gather with the
+// composite weights Wc[tap][k] = sum_j W_final[j][tap] * W_fusion[j][k].  The 64-channel tensor `f` (written and read once per
+// pixel: 2 x 128 MB per 1024 x 1024 bf16 image) never exists, and a skinny 192 -> 1 contraction is VALU work, not a GEMM tile.
+// The one subtlety is the border: final_conv zero-pads f, and f = W_fusion*gather + b_fusion is NOT zero where gather is, so
+// the fusion bias enters per tap and only for taps that fall inside the image:
+//   I_delta[p] = b_final + sum_{tap: p+tap inside} ( cb[tap] + Wc[tap] . gather[p+tap] ),   cb[tap] = W_final[:, tap] . b_fusion
+// Nearest up-sampling is resolved on read exactly as in the convolution kernels (src = min(floor(dst * in/out), in - 1)):
+// the dot products T_s[q][tap] = Wc[tap][source s] . d_s[q] are taken once per SOURCE pixel q of each pyramid level (phase 1,
+// eight lanes per pixel, 16 bytes per lane), and an output pixel sums 27 of them (phase 2).  Phase 3 forms S with the
+// band axis on the lanes.  Only the training forward keeps the two layers apart (their weight gradients need f).
+#include "loss_kernels.h"
+
+namespace {
+const int TT = 16;                       // output tile edge
+const int R3 = TT + 2;                   // full-resolution pixels per tile edge incl. the 3x3 halo
+const int R2MAX = 12, R1MAX = 8;         // source pixels per edge of the 1/2 and 1/4 level (exact x2 / x4: 10 and 6)
+}
+
+struct TailParams {
+    const void* d1; const void* d2; const void* d3;     // NHWC, 64 channels per pixel (cstride 64), bf16 or fp32
+    int H, W, H2, W2, H4, W4, N;
+    float sy2, sx2, sy4, sx4;                            // nearest scales in / out (1.0f = same size)
+    const float* wc;                                     // [3 sources][9 taps][64] composite weights, then cb[9], then b_final
+    const float* RL; int rl_cs;                          // R_low | I_low (fp32)
+    float* D; int d_cs;                                  // I_delta out
+    float* S; int s_cs;                                  // enhanced cube out
+    int B;
+};
+
+// Wc / cb / b_final from the two layers' parameters (re-made every forward: the weights may have been stepped)
+__global__ void tail_weights_kernel(const float* __restrict__ wf, const float* __restrict__ bf, const float* __restrict__ wl,
+                                    const float* __restrict__ bl, float* __restrict__ out)
+{
+    // wf: feature_fusion weight (64, 192, 1, 1), bf: its bias (64); wl: final_conv weight (1, 64, 3, 3), bl: its bias (1)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3 * 9 * 64) {
+        const int s = i / (9 * 64), tap = (i / 64) % 9, k = i % 64;
+        float a = 0.f;
+        for (int j = 0; j < 64; ++j) a += wl[j * 9 + tap] * wf[j * 192 + s * 64 + k];
+        out[i] = a;
+    } else if (i < 3 * 9 * 64 + 9) {
+        const int tap = i - 3 * 9 * 64;
+        float a = 0.f;
+        for (int j = 0; j < 64; ++j) a += wl[j * 9 + tap] * bf[j];
+        out[i] = a;
+    } else if (i == 3 * 9 * 64 + 9) out[i] = bl[0];
+}
+
+__device__ __forceinline__ int nearest_src(int v, float s, int n) { return min((int)floorf((float)v * s), n - 1); }
+
+template <bool BF16>
+__device__ __forceinline__ void load8(const void* base, size_t pix, int c8, float* v)
+{
+    if (BF16) {
+        const uint4 u = *(const uint4*)((const unsigned short*)base + pix * 64 + c8);
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    } else {
+        const f32x4 a = *(const f32x4*)((const float*)base + pix * 64 + c8), b = *(const f32x4*)((const float*)base + pix * 64 + c8 + 4);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void tail_kernel(const TailParams p)
+{
+    __shared__ __attribute__((aligned(16))) float wcs[3 * 9 * 64 + 16];
+    __shared__ float T3[R3 * R3 * 9], T2[R2MAX * R2MAX * 9], T1[R1MAX * R1MAX * 9];
+    __shared__ float Dt[TT * TT];
+    const int tid = threadIdx.x;
+    const int tiles_x = (p.W + TT - 1) / TT, tiles_y = (p.H + TT - 1) / TT;
+    const int n = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x % (tiles_x * tiles_y);
+    const int y0 = (tr / tiles_x) * TT, x0 = (tr % tiles_x) * TT;
+    for (int i = tid; i < 3 * 9 * 64 + 10; i += 256) wcs[i] = p.wc[i];
+    // source-pixel windows of the two coarse levels that the (clamped) full-resolution window maps to
+    const int vy_lo = max(y0 - 1, 0), vy_hi = min(y0 + TT, p.H - 1), vx_lo = max(x0 - 1, 0), vx_hi = min(x0 + TT, p.W - 1);
+    const int y2lo = nearest_src(vy_lo, p.sy2, p.H2), x2lo = nearest_src(vx_lo, p.sx2, p.W2);
+    const int n2y = nearest_src(vy_hi, p.sy2, p.H2) - y2lo + 1, n2x = nearest_src(vx_hi, p.sx2, p.W2) - x2lo + 1;
+    const int y1lo = nearest_src(vy_lo, p.sy4, p.H4), x1lo = nearest_src(vx_lo, p.sx4, p.W4);
+    const int n1y = nearest_src(vy_hi, p.sy4, p.H4) - y1lo + 1, n1x = nearest_src(vx_hi, p.sx4, p.W4) - x1lo + 1;
+    __syncthreads();
+
+    // ---- phase 1: nine dot products per source pixel, eight lanes per pixel (8 channels = 16 B bf16 / 32 B fp32 each) ----
+    const int sub = tid & 7, slot = tid >> 3;
+    const int n3 = R3 * R3, n2 = n2y * n2x, n1 = n1y * n1x, items = n3 + n2 + n1;
+    for (int it = slot; it < ((items + 31) & ~31); it += 32) {
+        float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float* dst = nullptr;
+        if (it < items) {
+            const void* base; size_t pix; const float* w; bool inside = true;
+            if (it < n3) {
+                const int yy = y0 - 1 + it / R3, xx = x0 - 1 + it % R3;
+                inside = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+                base = p.d3; pix = ((size_t)n * p.H + yy) * p.W + xx; w = wcs + 2 * 9 * 64; dst = T3 + it * 9;
+            } else if (it < n3 + n2) {
+                const int q = it - n3, yy = y2lo + q / n2x, xx = x2lo + q % n2x;
+                base = p.d2; pix = ((size_t)n * p.H2 + yy) * p.W2 + xx; w = wcs + 1 * 9 * 64; dst = T2 + q * 9;
+            } else {
+                const int q = it - n3 - n2, yy = y1lo + q / n1x, xx = x1lo + q % n1x;
+                base = p.d1; pix = ((size_t)n * p.H4 + yy) * p.W4 + xx; w = wcs; dst = T1 + q * 9;
+            }
+            if (inside) {
+                float v[8];
+                load8<BF16>(base, pix, sub * 8, v);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const f32x4 wa = *(const f32x4*)(w + t * 64 + sub * 8), wb = *(const f32x4*)(w + t * 64 + sub * 8 + 4);
+                    acc[t] = v[0] * wa[0] + v[1] * wa[1] + v[2] * wa[2] + v[3] * wa[3] + v[4] * wb[0] + v[5] * wb[1] + v[6] * wb[2] + v[7] * wb[3];
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { float a = acc[t]; a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); acc[t] = a; }
+        if (dst) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) if (sub == (t & 7)) dst[t] = acc[t];
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: one output pixel per thread ----
+    {
+        const int ty = tid >> 4, tx = tid & 15, y = y0 + ty, x = x0 + tx;
+        float d = 0.f;
+        if (y < p.H && x < p.W) {
+            d = wcs[3 * 9 * 64 + 9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int qy = y + t / 3 - 1, qx = x + t % 3 - 1;
+                if (qy < 0 || qy >= p.H || qx < 0 || qx >= p.W) continue;           // zero padding of f (and of the gather)
+                const int i3 = (qy - y0 + 1) * R3 + (qx - x0 + 1);
+                const int i2 = (nearest_src(qy, p.sy2, p.H2) - y2lo) * n2x + (nearest_src(qx, p.sx2, p.W2) - x2lo);
+                const int i1 = (nearest_src(qy, p.sy4, p.H4) - y1lo) * n1x + (nearest_src(qx, p.sx4, p.W4) - x1lo);
+                d += wcs[3 * 9 * 64 + t] + T3[i3 * 9 + t] + T2[i2 * 9 + t] + T1[i1 * 9 + t];
+            }
+            p.D[(((size_t)n * p.H + y) * p.W + x) * p.d_cs] = d;
+        }
+        Dt[tid] = d;
+    }
+    __syncthreads();
+
+    // ---- phase 3: S = R * I_delta + R * I_low (model.py:233), four bands per lane ----
+    const int nq = p.s_cs >> 2;
+    for (int i = tid; i < TT * TT * nq; i += 256) {
+        const int px = i / nq, q = i - px * nq, y = y0 + (px >> 4), x = x0 + (px & 15);
+        if (y >= p.H || x >= p.W) continue;
+        const size_t pix = ((size_t)n * p.H + y) * p.W + x;
+        const float* rl = p.RL + pix * p.rl_cs;
+        const float dl = Dt[px], il = rl[p.B];
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        if (4 * q + 4 <= p.rl_cs) r = *(const f32x4*)(rl + 4 * q);
+        f32x4 s;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] = (4 * q + j < p.B) ? r[j] * dl + r[j] * il : 0.f;
+        *(f32x4*)(p.S + pix * p.s_cs + 4 * q) = s;
+    }
+}
+
+int ssie_launch_tail_weights(const float* wf, const float* bf, const float* wl, const float* bl, float* out, hipStream_t st)
+{
+    hipLaunchKernelGGL(tail_weights_kernel, dim3((3 * 9 * 64 + 10 + 255) / 256), dim3(256), 0, st, wf, bf, wl, bl, out);
+    return hipGetLastError() == hipSuccess ? 0 : 81;
+}
+
+int ssie_tail_supported(int H, int W, int H2, int W2, int H4, int W4)
+{
+    // the coarse-level windows must fit their LDS tables: (18 * in/out) + 2 source pixels per edge
+    auto span = [](int hv, int hs) { return (int)((double)(TT + 2) * hs / hv) + 2; };
+    return span(H, H2) <= R2MAX && span(W, W2) <= R2MAX && span(H, H4) <= R1MAX && span(W, W4) <= R1MAX;
+}
+
+int ssie_launch_tail(const void* d1, const void* d2, const void* d3, int bf16_in, int N, int H, int W, int H2, int W2, int H4, int W4,
+                     const float* wc, const float* RL, int rl_cs, float* D, int d_cs, float* S, int s_cs, int B, hipStream_t st)
+{
+    if (!ssie_tail_supported(H, W, H2, W2, H4, W4) || s_cs % 4 || rl_cs % 4) return 82;
+    TailParams p;
+    p.d1 = d1; p.d2 = d2; p.d3 = d3; p.H = H; p.W = W; p.H2 = H2; p.W2 = W2; p.H4 = H4; p.W4 = W4; p.N = N;
+    p.sy2 = (H2 == H) ? 1.f : (float)H2 / (float)H; p.sx2 = (W2 == W) ? 1.f : (float)W2 / (float)W;
+    p.sy4 = (H4 == H) ? 1.f : (float)H4 / (float)H; p.sx4 = (W4 == W) ? 1.f : (float)W4 / (float)W;
+    p.wc = wc; p.RL = RL; p.rl_cs = rl_cs; p.D = D; p.d_cs = d_cs; p.S = S; p.s_cs = s_cs; p.B = B;
+    const int tiles = N * ((H + TT - 1) / TT) * ((W + TT - 1) / TT);
+    if (bf16_in) hipLaunchKernelGGL(tail_kernel<true>, dim3(tiles), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(tail_kernel<false>, dim3(tiles), dim3(256), 0, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : 83;
+}

@@ -26,7 +26,9 @@ for _k in ("c_rec", "c_rf", "c_il", "c_id", "c_sp"):
     COEF_SETS["only_" + _k] = dict(ZERO, **{_k: O.JYU_COEFS[_k]})
 
 GEOMS = {"b5_16": (1, 5, 16, 16), "b31_32": (2, 31, 32, 32), "b31_64": (2, 31, 64, 64), "b8_24x40": (2, 8, 24, 40),
-         "b31_128": (1, 31, 128, 128), "b40_48": (1, 40, 48, 48)}      # 40 bands: more than one lane pass per pixel
+         "b31_128": (1, 31, 128, 128), "b40_48": (1, 40, 48, 48),       # 40 bands: 16 lanes per pixel in the tiled kernel
+         "b64_24x40": (1, 64, 24, 40), "b130_16x24": (1, 130, 16, 24),   # 32 and 64 lanes per pixel (shipped configs use 64 bands)
+         "b12_20x36": (2, 12, 20, 36)}                                   # B % 4 == 0: I_low sits in a float4 of its own
 
 
 @pytest.fixture(scope="module")
@@ -36,6 +38,15 @@ def H():
     from ssie_amd import hostlib
     assert hostlib.lib().ssie_device_ok() == 1
     return hostlib
+
+
+@pytest.fixture(params=["tiled", "half_wave"])
+def loss_kernel(H, request):
+    """both loss kernels through every case: the LDS-tiled one the plan runs, and the half-wave-per-pixel one it falls back
+    to for layouts the tiled kernel does not take (include/ssie_debug.h)"""
+    H.lib().ssie_debug_set_loss_generic(1 if request.param == "half_wave" else 0)
+    yield request.param
+    H.lib().ssie_debug_set_loss_generic(0)
 
 
 _cache = {}
@@ -81,7 +92,7 @@ def ambiguity(x, R, I, D, S, E):
 
 @pytest.mark.parametrize("coefset", list(COEF_SETS))
 @pytest.mark.parametrize("geom", list(GEOMS))
-def test_spatial_terms_elementwise(H, geom, coefset):
+def test_spatial_terms_elementwise(H, geom, coefset, loss_kernel):
     coefs = COEF_SETS[coefset]
     t32 = leaves(geom)
     scal, got = H.selfsup_loss_fwd_bwd(*[t.cuda() for t in t32], coefs)

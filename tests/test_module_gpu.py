@@ -128,7 +128,7 @@ def test_reference_method_names(M, tmp_path, monkeypatch):
     import ssie
     ssie.load()
     from ssie_amd import harness
-    bands = 5
+    bands = 8                       # the reference's SSIM treats the band axis as image width: needs more than 5 bands (11-tap window)
     for split in ("train", "eval", "test", "high"):
         os.makedirs(tmp_path / split)
     sio.savemat(str(tmp_path / "train" / "a.mat"), {"data": _cube(1, 40, 48, bands)})

@@ -26,6 +26,8 @@ CASES = {
     "b256_64": (1, 256, 64, 64, O.JYU_COEFS),        # BASELINE.json configs[2]: 256-band cubes
     "b8_24x40": (2, 8, 24, 40, O.JYU_COEFS),         # patch size that is not a power of two: direct-DFT Fourier loss
     "b5_96": (1, 5, 96, 96, O.DEFAULT_COEFS),
+    "b5_256": (1, 5, 256, 256, O.JYU_COEFS),         # patch_size 256 (model.py:456-473 takes any): three-pass Fourier loss
+    "b4_160x288": (1, 4, 160, 288, O.JYU_COEFS),     # above the LDS plane limit and not powers of two: three-pass direct DFT
 }
 GRAD_FLOOR = {"b256_64": 5e-3}     # 256 bands: cotangent noise 5-7e-2, deep-layer gradients see ~3e-3 of it
 
@@ -72,7 +74,7 @@ def forced_kernels(pkg, request):
 @pytest.mark.parametrize("case", list(CASES))
 def test_stagewise_parity(pkg, case, forced_kernels):
     H, _ = pkg
-    if forced_kernels and case in ("b5_16", "b256_64", "b5_96"):
+    if forced_kernels and case in ("b5_16", "b256_64", "b5_96", "b5_256", "b4_160x288"):
         pytest.skip("forced-kernel variant runs on the mid-size cases only (time)")
     n, bands, h, w, coefs = CASES[case]
     plan, table, flat, gflat, P = build_plan(H, n, bands, h, w, coefs)
@@ -188,12 +190,18 @@ def test_golden_reference_outputs(pkg, golden_dir, case):
             assert rel_l2(gr.cpu(), r) <= 6e-3, name
 
 
-@pytest.mark.parametrize("n,bands,h,w", [(1, 31, 200, 264), (2, 31, 50, 38), (1, 256, 128, 128)])
-def test_enhance_only_ragged_sizes(pkg, n, bands, h, w):
+@pytest.mark.parametrize("fused_tail", [1, 0])
+@pytest.mark.parametrize("n,bands,h,w", [(1, 31, 200, 264), (2, 31, 50, 38), (1, 256, 128, 128), (3, 8, 32, 64)])
+def test_enhance_only_ragged_sizes(pkg, n, bands, h, w, fused_tail):
     """Enhance-only path (test/inference entry, model.py:229-234) on sizes that are not multiples of the 16-pixel
-    tiles or of 8 (odd pyramid levels: the nearest up-sampling reads ceil-sized levels), and on full-size 256-band cubes."""
+    tiles or of 8 (odd pyramid levels: the nearest up-sampling reads ceil-sized levels), and on full-size 256-band cubes.
+    fused_tail = 1: feature_fusion + final_conv + S as one launch (tail_kernels.hip); 0: the three separate launches."""
     H, _ = pkg
-    plan, table, flat, gflat, P = build_plan(H, n, bands, h, w, O.JYU_COEFS)
+    H.lib().ssie_debug_set_fused_tail(fused_tail)
+    try:
+        plan, table, flat, gflat, P = build_plan(H, n, bands, h, w, O.JYU_COEFS)
+    finally:
+        H.lib().ssie_debug_set_fused_tail(1)
     x = O.synthetic_patches(n, bands, h, w)
     plan.enhance_fwd(x.cuda())
     torch.cuda.synchronize()

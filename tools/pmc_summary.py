@@ -1,0 +1,26 @@
+"""Dev tool: per-kernel means of the counters in rocprofv3 --pmc output directories.  usage: pmc_summary.py <dir> [<dir> ...] [--filter substr]"""
+import csv, glob, os, re, sys
+from collections import defaultdict
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    return re.sub(r"\(.*$", "", name).strip()
+
+dirs = [a for a in sys.argv[1:] if not a.startswith("--")]
+flt = None
+if "--filter" in sys.argv:
+    flt = sys.argv[sys.argv.index("--filter") + 1]
+    dirs = [d for d in dirs if d != flt]
+acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+for d in dirs:
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if flt and flt not in k:
+                continue
+            a = acc[k][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
+for k, cs in sorted(acc.items()):
+    n = max(v[1] for v in cs.values())
+    print(f"{k}  (dispatches {n})")
+    for c, (s, m) in sorted(cs.items()):
+        print(f"    {c:32s} {s / m:16.1f}")
