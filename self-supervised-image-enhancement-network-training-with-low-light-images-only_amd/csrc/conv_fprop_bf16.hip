@@ -36,6 +36,26 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 #define SSIE_X_KEEP(okr, val) (okr)
 #endif
 
+// Diagnostic build only (-DSSIE_STAMP, tools/stamp_bf16.py): wave 0's s_memtime per phase of the wide kernel, summed per workgroup:
+// [0] start [1] barrier wait, first step of a tile [2] barrier wait, other steps [3] end [4] DMA issue [5] epilogue + bookkeeping
+// [6] tiles [7] MFMA tap loops.  The shipped library never executes a stamp.
+#ifdef SSIE_STAMP
+__device__ unsigned long long* ssie_stamp_buf_h = nullptr;
+static unsigned long long* g_stamp_host_buf = nullptr;
+static int g_stamp_target = -1, g_stamp_launch = 0;
+extern "C" int ssie_debug_set_stamp_buffer_h(void* buf, int launch_index) { g_stamp_host_buf = (unsigned long long*)buf; g_stamp_target = launch_index; g_stamp_launch = 0; return 0; }
+#define HT_DECL unsigned long long st_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t_ = __builtin_amdgcn_s_memtime(); st_[0] = st_t_;
+#define HT_ACC(k) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_[k] += t_ - st_t_; st_t_ = t_; } while (0)
+#define HT_FLUSH do { st_[3] = __builtin_amdgcn_s_memtime(); if (ssie_stamp_buf_h && threadIdx.x == 0) \
+    for (int k_ = 0; k_ < 12; ++k_) ssie_stamp_buf_h[(size_t)blockIdx.x * 12 + k_] = st_[k_]; } while (0)
+#define HT_TILE st_[6] += 1
+#else
+#define HT_DECL
+#define HT_ACC(k)
+#define HT_FLUSH
+#define HT_TILE
+#endif
+
 __device__ __forceinline__ float ssie_bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
 
 // source address of 8 consecutive bf16 channels of virtual pixel (n, vy, vx), or the zero page
@@ -63,24 +83,34 @@ __device__ __forceinline__ f32x4 ssie_unpack4bf(uint2 u)
 // conv_device.h): lane (li, h) = output position li of the 2 x 16 M-tile, register r = channel 8*(r>>2) + 4h + (r&3).  Four
 // groups of four consecutive channels per lane: bf16 tensors move 8 bytes per group, fp32 outputs 16.
 //   opix = element offset of (this lane's pixel, channel out_coff); c0 = first channel of the N-tile + 4h
-__device__ __forceinline__ void ssie_epilogue_ht(const ConvParams& p, const f32x16& acc, size_t opix, int c0, bool pos_ok)
+// The bias comes from an LDS copy (bias_s, zero beyond Cout), NOT from global memory: vmcnt retires in issue order, so a global
+// load here would sit behind the next tile's whole halo + weight prefetch (issued during the last MFMA step) - in-kernel
+// stamps showed the epilogue of a 64 -> 64 3x3 bf16 tile waiting 19k cycles, half the tile's time, for exactly that.
+__device__ __forceinline__ void ssie_epilogue_ht(const ConvParams& p, const float* bias_s, const f32x16& acc, size_t opix, int c0, bool pos_ok)
 {
     if (!pos_ok) return;
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 v[4];
     bool full[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int c = c0 + 8 * g;
         full[g] = c + 4 <= p.Cout;
-        const f32x4 b = (p.bias && full[g]) ? *(const f32x4*)(p.bias + c) : z4;
+        const f32x4 b = *(const f32x4*)(bias_s + c);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float t = acc[4 * g + j] + b[j];
-            if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
-            else if (p.act == ACT_SIGMOID) t = 1.f / (1.f + expf(-t));
-            v[g][j] = t;
-        }
+        for (int j = 0; j < 4; ++j) v[g][j] = acc[4 * g + j] + b[j];
+    }
+    // ONE branch on the activation for the whole tile (inside the element loop hipcc emits the scalar compare-and-branch chain
+    // once per element: 64 x per wave and tile, ~12k cycles - stamped - against ~10k for the tile's MFMAs)
+    if (p.act == ACT_RELU) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[g][j] = fmaxf(v[g][j], 0.f);
+    } else if (p.act == ACT_SIGMOID) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[g][j] = __frcp_rn(1.f + __expf(-v[g][j]));
     }
     if (p.out2) {
         unsigned short* o2 = (unsigned short*)p.out2 + opix + c0;
@@ -113,7 +143,7 @@ __device__ __forceinline__ void ssie_epilogue_ht(const ConvParams& p, const f32x
         for (int j = 0; j < 3; ++j) {
             if (c + j >= p.Cout) break;
             const size_t o = opix + c + j;
-            float t = acc[4 * g + j] + (p.bias ? p.bias[c + j] : 0.f);
+            float t = acc[4 * g + j] + bias_s[c + j];
             if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
             else if (p.act == ACT_SIGMOID) t = 1.f / (1.f + expf(-t));
             if (p.out2) ((unsigned short*)p.out2)[o] = ssie_f2bf(t);
@@ -138,6 +168,8 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16_kernel(const ConvParam
     f32x4* Bs0 = As0 + 2 * HP4;                     // [2][BSZ]
     int* tapoff = (int*)(Bs0 + 2 * BSZ);
     int* s_next = tapoff + SSIE_MAX_TAPS;
+    float* bias_s = (float*)(s_next + 4);          // [Cout_pad]: the bias vector, staged once (see ssie_epilogue_ht)
+    float* zero_bias_s = bias_s + p.Cout_pad;      // [Cout_pad] zeros: edge tiles of the lean path (bias already in the accumulators)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, li = lane & 31;
@@ -146,6 +178,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16_kernel(const ConvParam
 
     for (int t = tid; t < p.ntaps; t += NTHR)
         tapoff[t] = ((int)p.tap_dy[t] - p.min_dy) * p.hp_w + ((int)p.tap_dx[t] - p.min_dx);
+    for (int t = tid; t < p.Cout_pad; t += NTHR) { bias_s[t] = (p.bias && t < p.Cout) ? p.bias[t] : 0.f; zero_bias_s[t] = 0.f; }
 
     int pixbase[MT];
 #pragma unroll
@@ -267,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16_kernel(const ConvParam
             const int mt = wm * MT + m;
             bool ok;
             const size_t opix = ssie_epilogue_pos(p, n, a0 + 2 * mt, b0, li, ok);
-            ssie_epilogue_ht(p, acc[m], opix, co0 + wn * 32 + 4 * h, ok);
+            ssie_epilogue_ht(p, bias_s, acc[m], opix, co0 + wn * 32 + 4 * h, ok);
         }
         n = nn; a0 = na0; b0 = nb0; co0 = nco0; tile = ntile;
     }
@@ -292,12 +325,15 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16w_kernel(const ConvPara
     f32x4* Bs0 = As0 + 2 * HP4;                     // [2][BSZ]
     int* tapoff = (int*)(Bs0 + 2 * BSZ);
     int* s_next = tapoff + SSIE_MAX_TAPS;
+    float* bias_s = (float*)(s_next + 4);          // [Cout_pad]: the bias vector, staged once (see ssie_epilogue_ht)
+    float* zero_bias_s = bias_s + p.Cout_pad;      // [Cout_pad] zeros: edge tiles of the lean path (bias already in the accumulators)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, li = lane & 31;
 
     for (int t = tid; t < p.ntaps; t += NTHR)
         tapoff[t] = ((int)p.tap_dy[t] - p.min_dy) * p.hp_w + ((int)p.tap_dx[t] - p.min_dx);
+    for (int t = tid; t < p.Cout_pad; t += NTHR) { bias_s[t] = (p.bias && t < p.Cout) ? p.bias[t] : 0.f; zero_bias_s[t] = 0.f; }
 
     int pixbase[MT];
 #pragma unroll
@@ -337,6 +373,9 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16w_kernel(const ConvPara
     }
     // DMA the operands of step (CHUNK, G) of tile (N_, A0_, B0_, CO0_): weights into B buffer BUF, and (first tap group
     // of a chunk only) the halo tile into A buffer ABUF
+    // Interior tiles of plain (not up-sampled) sources whose channel count fills whole chunks take a lean address path: the
+    // halo slot's address is ONE uniform base per step plus a per-lane offset of two multiplies - no bounds checks, no clamping,
+    // no 64-bit vector arithmetic (the DMA-issue phase was ~20 % of a tile's time on the general path).
 #define HW_PREFETCH(CHUNK, G, N_, A0_, B0_, CO0_, BUF, ABUF)                                                        \
     {                                                                                                         \
         if ((G) == 0) {                                                                                       \
@@ -344,22 +383,32 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16w_kernel(const ConvPara
             const bool up_ = s_.sy != 1.f || s_.sx != 1.f;                                                    \
             const int vy0_ = (A0_) + p.min_dy, vx0_ = (B0_) + p.min_dx;                                       \
             f32x4* abuf_ = As0 + (ABUF) * HP4;                                                                \
-            _Pragma("unroll") for (int i_ = 0; i_ < NA2; ++i_) {                                              \
-                if (tid + i_ * NTHR < HP4) {                                                                  \
-                    const f32x4* g_ = ssie_virtual_addr_h(s_, up_, (N_), vy0_ + ahy[i_], vx0_ + ahx[i_], p.Hv, p.Wv, \
-                                                          (CHUNK) * CKH + 8 * aj[i_] - s_.cbeg);              \
-                    GLDS16(g_, abuf_ + i_ * NTHR + wave * 64);                                                \
+            const bool lean_ = !up_ && (s_.C & 31) == 0 && vy0_ >= 0 && vx0_ >= 0 && vy0_ + p.hp_h <= p.Hv && vx0_ + p.hp_w <= p.Wv; \
+            if (lean_) {                                                                                      \
+                const unsigned short* sb_ = (const unsigned short*)s_.ptr +                                   \
+                    ((size_t)((N_) * s_.Hs + vy0_) * s_.Ws + vx0_) * s_.cstride + s_.coff + (CHUNK) * CKH - s_.cbeg; \
+                _Pragma("unroll") for (int i_ = 0; i_ < NA2; ++i_) {                                          \
+                    if (tid + i_ * NTHR < HP4) {                                                              \
+                        const int lo_ = (ahy[i_] * s_.Ws + ahx[i_]) * s_.cstride + 8 * aj[i_];               \
+                        GLDS16(sb_ + lo_, abuf_ + i_ * NTHR + wave * 64);                                     \
+                    }                                                                                         \
+                }                                                                                             \
+            } else {                                                                                          \
+                _Pragma("unroll") for (int i_ = 0; i_ < NA2; ++i_) {                                          \
+                    if (tid + i_ * NTHR < HP4) {                                                              \
+                        const f32x4* g_ = ssie_virtual_addr_h(s_, up_, (N_), vy0_ + ahy[i_], vx0_ + ahx[i_], p.Hv, p.Wv, \
+                                                              (CHUNK) * CKH + 8 * aj[i_] - s_.cbeg);          \
+                        GLDS16(g_, abuf_ + i_ * NTHR + wave * 64);                                            \
+                    }                                                                                         \
                 }                                                                                             \
             }                                                                                                 \
         }                                                                                                     \
         const int t0_ = (G) * SSIE_TG;                                                                        \
-        const int pieces_ = min(SSIE_TG, p.ntaps - t0_) * 4 * BN / 64;                                        \
+        const int pieces_ = min(SSIE_TG, p.ntaps - t0_) * 4;              /* rows of BN = 64 slots: one piece each */ \
         const f32x4* wsrc_ = (const f32x4*)p.wpacked + ((size_t)((CHUNK) * p.ntaps + t0_) * 4) * p.Cout_pad + (CO0_); \
         f32x4* bbuf_ = Bs0 + (BUF) * BSZ;                                                                     \
-        for (int q_ = wave; q_ < pieces_; q_ += NW) {                                                         \
-            const int slot_ = q_ * 64 + lane;                                                                 \
-            GLDS16(wsrc_ + (size_t)(slot_ / BN) * p.Cout_pad + (slot_ % BN), bbuf_ + q_ * 64);                \
-        }                                                                                                     \
+        for (int q_ = wave; q_ < pieces_; q_ += NW)                                                           \
+            GLDS16(wsrc_ + (size_t)q_ * p.Cout_pad + lane, bbuf_ + q_ * 64);                                  \
     }
 
     int tile = blockIdx.x;
@@ -370,10 +419,25 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16w_kernel(const ConvPara
     int a_cur = 0;          // A buffer holding the halo tile of the step about to be computed
     HW_PREFETCH(0, 0, n, a0, b0, co0, 0, 0)
     int fetched = 0x7fffffff;
+    HT_DECL
     // The two waves of a SIMD (w and w+4) run the same program; issuing the next step's DMA (address VALU work) at
     // the same moment would leave the SIMD's MFMA pipe idle.  Waves 4-7 therefore issue it in the middle of their
     // tap loop while waves 0-3 issue it up front.
     const bool late_prefetch = false;   // measured: issuing the DMA inside the tap loop (waves 4-7) was 5-25 % SLOWER
+
+    // LEAN EPILOGUE (most layers: bf16 output, ReLU or none, no residual / second output, Cout a multiple of 32, tile inside
+    // the image).  The kernel is bound by the non-MFMA instructions its two waves per SIMD issue (stamps: the general
+    // epilogue took 8-12k cycles per tile against ~10k for the tile's MFMAs), so everything tile-invariant is hoisted:
+    //   * the bias enters as the accumulators' initial value (read from LDS right after the step-0 barrier, where vmcnt has
+    //     been drained anyway - a ds_read later forces hipcc to drain the in-flight LDS-DMA prefetch first)
+    //   * the lane's element offsets inside the tile are computed once per kernel; a tile contributes ONE uniform base
+    //   * per accumulator what is left is 8 packed max, 8 packed converts and 4 eight-byte stores
+    const bool lean = p.out_bf16 && !p.addsrc && !p.out2 && (p.Cout % 32) == 0 && p.act != ACT_SIGMOID;
+    const float relu_lo = p.act == ACT_RELU ? 0.f : -3.0e38f;
+    int lane_off[MT];                                   // element offset of (this lane's pixel of M-tile m, channel 4h) inside a tile
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+        lane_off[m] = ((2 * wave + (li >> 4)) * p.so * p.Wout + (16 * m + (li & 15)) * p.so) * p.out_cstride + 4 * h;
 
     while (tile < total_tiles) {
         f32x16 acc[MT][NT];
@@ -399,8 +463,22 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16w_kernel(const ConvPara
             }
             // ONE barrier per step: my DMA for this step has landed (vmcnt) and every wave has finished reading the
             // other buffer (previous step), which the prefetch below overwrites
+            HT_ACC(5);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            HT_ACC(step == 0 ? 1 : 2);
+            if (step == 0 && lean) {
+#pragma unroll
+                for (int c = 0; c < NT; ++c)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const f32x4 b = *(const f32x4*)(bias_s + co0 + 32 * c + 8 * g4 + 4 * h);
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[m][c][4 * g4 + j] = b[j];
+                    }
+            }
             if (step == (nsteps > 1 ? 1 : 0)) {
                 ntile = *s_next;
                 if (ntile < total_tiles) HW_DECODE(ntile, nn, na0, nb0, nco0)
@@ -415,6 +493,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16w_kernel(const ConvPara
                 else if (ntile < total_tiles) HW_PREFETCH(0, 0, nn, na0, nb0, nco0, buf ^ 1, a_nxt)       \
             }
             HW_ISSUE_NEXT
+            HT_ACC(4);
 
             const char* Ab = (const char*)(As0 + a_cur * HP4);
             const f32x4* Bl = Bs0 + buf * BSZ + h * BN + li;          // this lane's column of the weight group
@@ -427,7 +506,26 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16w_kernel(const ConvPara
 #define W_MFMA(BF, AF)                                                                                    \
             _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_)                                             \
             _Pragma("unroll") for (int c_ = 0; c_ < NT; ++c_) acc[m_][c_] = MFMA_BF16(BF[c_], AF[m_], acc[m_][c_]);
-            {
+            // the tap loop with a COMPILE-TIME trip count: aaddr[][] then stays in fixed registers and the fragment reads of
+            // tap t+1 are in flight under the MFMAs of tap t.  (With a run-time bound hipcc keeps the loop rolled, indexes the
+            // address array through s_set_gpr_idx and drains lgkmcnt(0) every tap - the kernel was instruction-bound.)
+#define W_TAPS(TG_)                                                                                       \
+            {                                                                                             \
+                f32x4 bX[NT], bY[NT], aX[MT], aY[MT];                                                     \
+                W_LD(bX, aX, 0, 0)                                                                        \
+                _Pragma("unroll") for (int tl = 0; tl < TG_; ++tl) {                                      \
+                    W_LD(bY, aY, tl, 1)                                                                   \
+                    W_MFMA(bX, aX)                                                                        \
+                    if (tl + 1 < TG_) W_LD(bX, aX, (tl + 1 < TG_ ? tl + 1 : 0), 0)                         \
+                    W_MFMA(bY, aY)                                                                        \
+                }                                                                                         \
+            }
+            switch (tg) {
+            case 9: W_TAPS(9) break;
+            case 4: W_TAPS(4) break;
+            case 2: W_TAPS(2) break;
+            case 1: W_TAPS(1) break;
+            default: {
                 f32x4 bX[NT], bY[NT], aX[MT], aY[MT];
                 W_LD(bX, aX, 0, 0)
 #pragma unroll
@@ -438,7 +536,9 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16w_kernel(const ConvPara
                     if (tl + 1 < SSIE_TG && tl + 1 < tg) W_LD(bX, aX, (tl + 1 < SSIE_TG ? tl + 1 : 0), 0)
                     W_MFMA(bY, aY)
                 }
+            } break;
             }
+#undef W_TAPS
 #undef W_LD
 #undef W_MFMA
 #undef HW_ISSUE_NEXT
@@ -446,19 +546,41 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16w_kernel(const ConvPara
             if (tid == 0 && step == 0 && nsteps > 1 && p.tile_counter)
                 fetched = (int)gridDim.x + atomicAdd(p.tile_counter, 1);
             chunk = nchunk; g = ng; a_cur = a_nxt;
+            HT_ACC(7);
         }
 
         // epilogue: wave w holds tile rows 2w, 2w+1; M-tile m = columns 16m .. 16m+15, N-tile c = channels 32c .. 32c+31;
         // D^T = W x X above, so lane li = position, registers = channels (ssie_epilogue_ht)
+        HT_ACC(8);
+        const bool inside = a0 + TH <= p.Ho && b0 + TWW <= p.Wo && (a0 + TH - 1) * p.so + p.py < p.Hout && (b0 + TWW - 1) * p.so + p.px < p.Wout;
+        if (lean && inside) {
+            unsigned short* tbase = (unsigned short*)p.out + ((size_t)(n * p.Hout + a0 * p.so + p.py) * p.Wout + b0 * p.so + p.px) * p.out_cstride + p.out_coff + co0;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            bool ok;
-            const size_t opix = ssie_epilogue_pos(p, n, a0 + 2 * wave, b0 + 16 * m, li, ok);
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int c = 0; c < NT; ++c) ssie_epilogue_ht(p, acc[m][c], opix, co0 + c * 32 + 4 * h, ok);
+                for (int c = 0; c < NT; ++c)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const f32x16& a = acc[m][c];
+                        const uint2 u = make_uint2(ssie_pack2bf(fmaxf(a[4 * g4], relu_lo), fmaxf(a[4 * g4 + 1], relu_lo)),
+                                                   ssie_pack2bf(fmaxf(a[4 * g4 + 2], relu_lo), fmaxf(a[4 * g4 + 3], relu_lo)));
+                        if (SSIE_X_KEEP(true, a[0])) *(uint2*)(tbase + lane_off[m] + 32 * c + 8 * g4) = u;
+                    }
+        } else {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                bool ok;
+                const size_t opix = ssie_epilogue_pos(p, n, a0 + 2 * wave, b0 + 16 * m, li, ok);
+#pragma unroll
+                for (int c = 0; c < NT; ++c) ssie_epilogue_ht(p, lean ? zero_bias_s : bias_s, acc[m][c], opix, co0 + c * 32 + 4 * h, ok);
+            }
         }
+        HT_ACC(9);
         n = nn; a0 = na0; b0 = nb0; co0 = nco0; tile = ntile;
+        HT_TILE;
     }
+    HT_ACC(5);
+    HT_FLUSH;
 #undef HW_PREFETCH
 #undef HW_DECODE
 }
@@ -473,7 +595,7 @@ INST_H(2, 3, 16) INST_H(2, 5, 16) INST_H(1, 3, 16) INST_H(1, 5, 16) INST_H(2, 5,
 
 static size_t lds_bytes_h(const ConvParams& p, int nt)
 {
-    return 2 * ((size_t)p.hp_h * p.hp_w * 64 + (size_t)SSIE_TG * 4 * 32 * nt * 16) + (size_t)SSIE_MAX_TAPS * 4 + 16;
+    return 2 * ((size_t)p.hp_h * p.hp_w * 64 + (size_t)SSIE_TG * 4 * 32 * nt * 16) + (size_t)SSIE_MAX_TAPS * 4 + 16 + (size_t)p.Cout_pad * 8;
 }
 
 template <int NT, int NA2, int TH>
@@ -488,8 +610,14 @@ static int launch_h_t(const ConvParams& p, size_t lds, hipStream_t st)
 }
 
 // p must come from ssie_make_conv_bf16 (th = 16 for stride 1, 8 for stride 2; 32-channel chunks)
-int ssie_launch_fprop_bf16(const ConvParams& p, hipStream_t st)
+int ssie_bf16_dynamic_queue = 0;      // see below
+int ssie_launch_fprop_bf16(const ConvParams& p_in, hipStream_t st)
 {
+    // Static tile assignment (tile += gridDim.x).  The dynamic queue of the fp32 kernels draws every tile with a returning
+    // atomic on ONE counter; a bf16 tile is ~16x shorter than an fp32 one, so at 2048 tiles per launch the same-address
+    // atomics (serialised at the memory side) and their in-order return behind the prefetch DMA set the pace.
+    ConvParams p = p_in;
+    if (!ssie_bf16_dynamic_queue) p.tile_counter = nullptr;
     const int nt = (p.Cout_pad % 64 == 0) ? 2 : 1;
     const int na2 = (p.hp_h * p.hp_w * 4 + 511) / 512;
     const size_t lds = lds_bytes_h(p, nt);
@@ -503,8 +631,15 @@ int ssie_launch_fprop_bf16(const ConvParams& p, hipStream_t st)
         }
         const size_t tiles = (size_t)p.N * p.tiles_y * p.tiles_x * p.co_blocks;
         const dim3 grid((unsigned)(tiles < 256 ? tiles : 256));
+#ifdef SSIE_STAMP
+        const bool stamp_this = g_stamp_host_buf && g_stamp_launch++ == g_stamp_target;
+        if (stamp_this) { hipStreamSynchronize(st); hipMemcpyToSymbol(HIP_SYMBOL(ssie_stamp_buf_h), &g_stamp_host_buf, sizeof(void*)); }
+#endif
         if (p.nsrc == 1) hipLaunchKernelGGL((conv_fprop_bf16w_kernel<5, true>), grid, dim3(512), lds, st, p);
         else hipLaunchKernelGGL((conv_fprop_bf16w_kernel<5, false>), grid, dim3(512), lds, st, p);
+#ifdef SSIE_STAMP
+        if (stamp_this) { hipStreamSynchronize(st); void* z = nullptr; hipMemcpyToSymbol(HIP_SYMBOL(ssie_stamp_buf_h), &z, sizeof(void*)); }
+#endif
         return hipGetLastError() == hipSuccess ? 0 : 65;
     }
     if (p.th == 8) return nt == 2 ? launch_h_t<2, 5, 8>(p, lds, st) : 63;

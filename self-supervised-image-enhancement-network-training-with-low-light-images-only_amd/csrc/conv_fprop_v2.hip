@@ -153,6 +153,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fprop_v2_kernel(const ConvPar
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        // the bias is fetched HERE, ahead of the step-0 barrier that drains vmcnt anyway: vmcnt retires in issue order, so the
+        // same load issued in the epilogue would wait behind the next tile's whole halo + weight prefetch
+        const float bv_tile = (p.bias && co0 + wn * 32 + li < p.Cout) ? p.bias[co0 + wn * 32 + li] : 0.f;
         int ntile = 0x7fffffff;
         int nn = n, na0 = a0, nb0 = b0, nco0 = co0;
 
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fprop_v2_kernel(const ConvPar
         // epilogue (identical mapping to the v1 kernel; TH = 16 so M-tile mt covers tile rows 2*mt, 2*mt+1)
         const int co = co0 + wn * 32 + li;
         if (co < p.Cout) {
-            const float bv = p.bias ? p.bias[co] : 0.f;
+            const float bv = bv_tile;
             const long rowstride = (long)p.so * p.Wout * p.out_cstride;
             const long pixstride = (long)p.so * p.out_cstride;
             const bool full = a0 + TH <= p.Ho && b0 + SSIE_TW <= p.Wo &&
@@ -385,6 +388,10 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_v2w_kernel(const ConvParams
             for (int c = 0; c < NT; ++c)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][c][r] = 0.f;
+        // bias fetched ahead of the step-0 barrier (see conv_fprop_v2_kernel)
+        float bv_tile[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) bv_tile[c] = (p.bias && co0 + c * 32 + li < p.Cout) ? p.bias[co0 + c * 32 + li] : 0.f;
         int ntile = 0x7fffffff;
         int nn = n, na0 = a0, nb0 = b0, nco0 = co0;
 
@@ -463,7 +470,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_v2w_kernel(const ConvParams
             for (int c = 0; c < NT; ++c) {
                 const int co = co0 + c * 32 + li;
                 if (co >= p.Cout) continue;
-                const float bv = p.bias ? p.bias[co] : 0.f;
+                const float bv = bv_tile[c];
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     const int arow = a0 + 2 * wave, bcol = b0 + 16 * m + 4 * h;
