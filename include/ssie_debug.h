@@ -36,8 +36,10 @@ void ssie_debug_set_fprop_v2_split(int on);             /* [1] 0 = one 8-wave wo
 void ssie_debug_set_fprop_v2_split_min_tiles(int v);    /* [1024] */
 void ssie_debug_set_fprop_wgs_per_cu(int v);
 void ssie_debug_set_fused_tail(int on);                 /* [1] 0 = inference keeps feature_fusion / final_conv / compose as separate launches (plans bound afterwards) */
+void ssie_debug_set_skinny_final(int on);               /* [1] 0 = final_conv (64 -> 1) forward / gradients on the MFMA tile kernels (plans created afterwards) */
 void ssie_debug_set_loss_generic(int v);                 /* [0] 1 = the half-wave-per-pixel loss kernel instead of the tiled one */
-void ssie_debug_set_wgrad_sliding(int v);               /* [1] 0 = generic wgrad K loop everywhere */
+void ssie_debug_set_wgrad_sliding(int v);
+void ssie_debug_set_wgrad_rows2(int v);                 /* [1] 0 = one 9x9 kernel row per workgroup (gradient tile re-read 9x instead of 5x) */               /* [1] 0 = generic wgrad K loop everywhere */
 /* (diagnostic builds compiled with -DSSIE_STAMP additionally export two s_memtime stamp-buffer setters, see tools/stamp_*.py;
  * the shipped library has no stamp code) */
 

@@ -46,11 +46,24 @@ def parse_args(argv=None):
     ap = argparse.ArgumentParser(description="Parse config from YAML and command-line.")
     ap.add_argument("--config", type=str, default="./config/config_outdoor_jyu.yml")
     ap.add_argument("--timestamp", type=str, default=None, help="checkpoint timestamp to test (phase=test)")
+    ap.add_argument("--preset", type=str, default=None, help="preset name inside a presets file (config/presets.yml)")
     for k, v in DEFAULTS.items():
         ap.add_argument(f"--{k}", type=_flag_type(v), default=None)
     args = ap.parse_args(argv)
     with open(args.config, "r") as f:
         cfg = yaml.safe_load(f) or {}
+    if "presets" in cfg:                                  # config/presets.yml: base file + the keys a preset changes
+        name = args.preset or "outdoor_jyu"
+        fold = None
+        if name not in cfg["presets"] and name[:-1] in cfg["presets"] and name[-1].isdigit():
+            name, fold = name[:-1], name[-1]              # indoor_li_et_al_cv3 -> preset indoor_li_et_al_cv, fold 3
+        if name not in cfg["presets"]:
+            raise SystemExit(f"unknown preset {args.preset!r}; available: {sorted(cfg['presets'])}")
+        with open(os.path.join(os.path.dirname(os.path.abspath(args.config)), cfg["base"]), "r") as f:
+            merged = yaml.safe_load(f) or {}
+        for k, v in (cfg["presets"][name] or {}).items():
+            merged[k] = v.format(fold=fold) if isinstance(v, str) and fold is not None else v
+        cfg = merged
     for k, dv in DEFAULTS.items():                       # CLI > YAML > default
         if getattr(args, k) is None:
             setattr(args, k, cfg.get(k, dv))

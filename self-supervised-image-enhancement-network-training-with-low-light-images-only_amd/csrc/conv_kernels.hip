@@ -294,13 +294,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     const int mi = pair / NI, ni = pair % NI;
     const int slice = blockIdx.x;
     const int cib = blockIdx.y / p.co_blocks, cob = blockIdx.y % p.co_blocks;
-    const int t0 = blockIdx.z * SSIE_TG;
+    // SW = 4 (9 x 9, two wave pairs per workgroup): the workgroup stages ONE gradient tile for TWO kernel rows (tap groups
+    // 2z and 2z + 1) and wave pair wsub takes row 2z + wsub over all positions, instead of both pairs splitting the positions
+    // of one row - the nine rows then re-read the gradient tile 5 times instead of 9 (1.5 GB -> 0.85 GB of L2-miss traffic per
+    // launch against 0.4 GB algorithmic) and the in-LDS reduction of the two K halves disappears.
+    const int ngroups_all = (p.ntaps + SSIE_TG - 1) / SSIE_TG;
+    const int grp0 = SW == 4 ? 2 * (int)blockIdx.z : (int)blockIdx.z;
+    const int ngrp_here = SW == 4 ? min(2, ngroups_all - grp0) : 1;
+    const int mygrp = grp0 + (SW == 4 ? wsub : 0);
+    const bool grp_valid = mygrp < ngroups_all;
+    const int t0 = (grp_valid ? mygrp : grp0) * SSIE_TG;
     const int tg = min(SSIE_TG, p.ntaps - t0);
     const int ci0 = cib * CIB, co0 = cob * COB;
 
-    // halo rows actually touched by this tap group (one kernel row of the 9x9 => 8 rows instead of 16)
+    // halo rows actually touched by this workgroup's tap group(s) (one kernel row of the 9x9 => 8 rows instead of 16)
     int gmin_dy = 127, gmax_dy = -127;
-    for (int tl = 0; tl < tg; ++tl) { const int dy = p.tap_dy[t0 + tl]; gmin_dy = min(gmin_dy, dy); gmax_dy = max(gmax_dy, dy); }
+    for (int tl = grp0 * SSIE_TG; tl < min((grp0 + ngrp_here) * SSIE_TG, p.ntaps); ++tl) { const int dy = p.tap_dy[tl]; gmin_dy = min(gmin_dy, dy); gmax_dy = max(gmax_dy, dy); }
     const int rows = (p.th - 1) * p.si + (gmax_dy - gmin_dy) + 1;
     const int HP = rows * p.hp_w;
 
@@ -308,8 +317,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     bool tval[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-        tval[u] = u < tg;
-        const int t = t0 + (tval[u] ? u : 0);
+        tval[u] = u < tg && grp_valid;
+        const int t = t0 + (u < tg ? u : 0);
         toff[u] = (((int)p.tap_dy[t] - gmin_dy) * p.hp_w + ((int)p.tap_dx[t] - p.min_dx)) * CIB + mi * 32 + li;
     }
     f32x16 acc[NU];
@@ -326,14 +335,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     const int tile_beg = slice * tps, tile_end = min(tile_beg + tps, p.tiles_total);
     constexpr int CI4 = CIB / 4, CO4 = COB / 4;
     // fused bias gradient (column sums of G): done once per co-block by the (ci block 0, tap group 0) workgroups
-    const bool do_bias = p.bias_slabs != nullptr && cib == 0 && blockIdx.z == 0;
+    const bool do_bias = p.bias_slabs != nullptr && cib == 0 && blockIdx.z == 0;      // (SW = 4: z = 0 covers rows 0 and 1; still one workgroup per co-block)
     constexpr int BROWS = 256 / COB;
     const int bcol = tid % COB, brow = tid / COB;
     float bsum = 0.f;
 
     // tile-invariant part of the halo staging: (row, column, channel quad) of this thread's LDS slots
     // ceil(max halo pixels of a sliding-window group * CI4 / 256): 10 x 18 or 8 x 24 at stride 1, 9 x 33 at stride 2
-    constexpr int MAXX = (SW == 3 ? 19 : 12) * CIB / 64 + (SW == 3 && CIB == 32 ? 1 : 0);
+    constexpr int MAXX = (SW == 3 ? 19 : SW == 4 ? 14 : 12) * CIB / 64 + (SW == 3 && CIB == 32 ? 1 : 0);
     constexpr int PT_MAX = 8 * SSIE_TW;
     const int nxs = HP * CI4;
     const bool up = s.sy != 1.f || s.sx != 1.f;
@@ -453,11 +462,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         //  co-resident workgroup's staging give all of it back: slower by 2-4 % in wall time, tools/stamp_wgrad.py)
         if constexpr (SW != 0) {
             // SW = 1: 3 x 3 stride 1, 2: one row of a 9 x 9 (stride 1), 3: 3 x 3 stride 2 (two new halo columns per step)
-            constexpr int NDY = SW == 2 ? 1 : 3, NDX = SW == 2 ? 9 : 3, SI = SW == 3 ? 2 : 1;
+            constexpr int NDY = (SW == 2 || SW == 4) ? 1 : 3, NDX = (SW == 2 || SW == 4) ? 9 : 3, SI = SW == 3 ? 2 : 1;
             static_assert(NU == 9, "sliding-window loop: groups of 9 taps");
-            for (int rp = wsub; rp < p.th / 2; rp += WSPLIT) {
+            constexpr int RSTEP = SW == 4 ? 1 : WSPLIT;                      // SW = 4: the wave pair owns its kernel row's whole tile
+            const int krow = SW == 4 ? mygrp - grp0 : 0;                     // this wave's kernel row inside the staged halo rows
+            for (int rp = (SW == 4 ? 0 : wsub); rp < (SW == 4 && !grp_valid ? 0 : p.th / 2); rp += RSTEP) {
                 const int row = 2 * rp + h;
-                const float* xr = Xs + row * SI * p.hp_w * CIB + mi * 32 + li; // halo (row*SI + d, column c) = xr[(d*hp_w + c)*CIB]
+                const float* xr = Xs + (row * SI + krow) * p.hp_w * CIB + mi * 32 + li; // halo (row*SI + d, column c) = xr[(d*hp_w + c)*CIB]
                 const float* gr = Gs + row * SSIE_TW * COB + ni * 32 + li;
                 const int rstr = p.hp_w * CIB;
                 float win[NDY][NDX];                                            // win[d][c % NDX] = halo column c of tap row d
@@ -513,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     }
     // waves that shared a tile pair add their partial accumulators through LDS (fixed order => deterministic), so the
     // workgroup writes ONE partial slab [slice][tap][ci_pad][co_pad]; row (M) = ci, col (N) = co
-    if (WSPLIT > 1) {
+    if (WSPLIT > 1 && SW != 4) {
         float* red = smem_f;                      // NPAIR x NU x 16 x 64 floats <= 36.9 KB, inside the staging area
         for (int w = 1; w < WSPLIT; ++w) {
             __syncthreads();
@@ -562,6 +573,7 @@ INST_WGRAD(32, 32, 9) INST_WGRAD(32, 32, 1)
                               template __global__ void conv_wgrad_kernel<CI, CO, 9, 2>(const WgradParams);
 INST_WGRAD_SW(64, 64) INST_WGRAD_SW(32, 64) INST_WGRAD_SW(64, 32) INST_WGRAD_SW(32, 32)
 template __global__ void conv_wgrad_kernel<64, 64, 9, 3>(const WgradParams);
+template __global__ void conv_wgrad_kernel<32, 64, 9, 4>(const WgradParams);
 
 // dst[co*s_co + ci*s_ci + t*s_t] (+)= sum_slices slab[slice][t][ci][co]; the trailing rows are the fused bias gradient
 // db[co] (+)= sum_slices bias_slab[slice][co].  Each thread owns 4 consecutive co (one 16-byte load per slice);
@@ -787,11 +799,13 @@ static int launch_wgrad_t(const WgradParams& p, hipStream_t st)
     if (lds > 160 * 1024) return 23;
     static bool set = false;
     if (!set) { hipFuncSetAttribute((const void*)conv_wgrad_kernel<CI, CO, NU, SW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
-    dim3 grid(p.nslices, p.ci_blocks * p.co_blocks, p.tap_groups);
+    dim3 grid(p.nslices, p.ci_blocks * p.co_blocks, p.tap_groups);      // SW = 4: tap_groups = pairs of kernel rows
     hipLaunchKernelGGL((conv_wgrad_kernel<CI, CO, NU, SW>), grid, dim3(256), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : 24;
 }
 
+int ssie_wgrad_rows2 = 1;        // A/B switch: 1 = two kernel rows per workgroup for the 9 x 9 weight gradient (SW = 4)
+extern "C" void ssie_debug_set_wgrad_rows2(int v) { ssie_wgrad_rows2 = v; }
 int ssie_wgrad_sliding = 1;      // A/B switch: 1 = sliding-window K loop for stride-1 3x3 / 9x9 layers
 extern "C" void ssie_debug_set_wgrad_sliding(int v) { ssie_wgrad_sliding = v; }
 
@@ -822,6 +836,8 @@ int ssie_launch_wgrad(const WgradParams& p, hipStream_t st)
         if (cib == 32 && cob == 32) return launch_wgrad_t<32, 32, 9, 1>(p, st);
     }
     if (sw == 3 && cib == 64 && cob == 64) return launch_wgrad_t<64, 64, 9, 3>(p, st);
+    if (sw == 2 && p.rows2 && cib == 32 && cob == 64) return launch_wgrad_t<32, 64, 9, 4>(p, st);
+    if (p.rows2) return 22;                               // geometry built for the two-row kernel but the tap list is not 9 x 9 rows
     if (sw == 2) {
         if (cib == 64 && cob == 64) return launch_wgrad_t<64, 64, 9, 2>(p, st);
         if (cib == 32 && cob == 64) return launch_wgrad_t<32, 64, 9, 2>(p, st);

@@ -166,6 +166,7 @@ PackDesc ssie_make_pack_bf16(const float* w, float* dst, int K, int N, const Tap
     return d;
 }
 
+extern int ssie_wgrad_rows2, ssie_wgrad_sliding;
 int ssie_make_wgrad(WgradParams& p, const SrcDesc& src, int N, int Hv, int Wv, int ci0_weight,
                     const float* g, int g_cstride, int g_coff, int Cout, int Ho, int Wo, int si,
                     const TapList& t, float* slabs, int target_wgs)
@@ -186,6 +187,9 @@ int ssie_make_wgrad(WgradParams& p, const SrcDesc& src, int N, int Hv, int Wv, i
     p.ci_pad = p.ci_blocks * cib; p.co_pad = p.co_blocks * cob;
     p.wsplit = 4 / ((cib / 32) * (cob / 32));
     p.tap_groups = ssie_ceil_div(t.n, SSIE_TG);
+    // 9 x 9 with two wave pairs per workgroup (32 x 64 blocks): one wave pair per kernel ROW, two rows per workgroup
+    p.rows2 = (ssie_wgrad_rows2 && ssie_wgrad_sliding && t.n == 81 && si == 1 && cib == 32 && cob == 64 && mxx - mnx == 8 && mxy - mny == 8) ? 1 : 0;
+    if (p.rows2) p.tap_groups = ssie_ceil_div(p.tap_groups, 2);
     p.tiles_y = ssie_ceil_div(Ho, p.th); p.tiles_x = ssie_ceil_div(Wo, SSIE_TW);
     p.tiles_total = N * p.tiles_y * p.tiles_x;
     int per = p.ci_blocks * p.co_blocks * p.tap_groups;

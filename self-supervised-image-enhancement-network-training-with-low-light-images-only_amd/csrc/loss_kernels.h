@@ -59,3 +59,8 @@ int ssie_tail_supported(int H, int W, int H2, int W2, int H4, int W4);
 int ssie_launch_tail_weights(const float* wf, const float* bf, const float* wl, const float* bl, float* out, hipStream_t st);
 int ssie_launch_tail(const void* d1, const void* d2, const void* d3, int bf16_in, int N, int H, int W, int H2, int W2, int H4, int W4,
                      const float* wc, const float* RL, int rl_cs, float* D, int d_cs, float* S, int s_cs, int B, hipStream_t st);
+// final_conv (3x3, 64 -> 1) of the training step as VALU kernels (tail_kernels.hip); f / Gf are (N,H,W,64) with 64 floats per pixel
+int ssie_launch_skinny_fwd(const float* f, const float* w, const float* bias, float* D, int d_cs, int N, int H, int W, hipStream_t st);
+int ssie_launch_skinny_dgrad(const float* gD, int d_cs, const float* w, float* Gf, int N, int H, int W, hipStream_t st);
+size_t ssie_skinny_wgrad_ws_floats();
+int ssie_launch_skinny_wgrad(const float* f, const float* gD, int d_cs, float* part, float* dw, float* db, int N, int H, int W, hipStream_t st);

@@ -46,7 +46,7 @@ struct Plan {
     std::map<std::string, BufInfo> bufs;
     size_t ws_floats = 0;
     size_t slab_off = 0, slab_off2 = 0, slab_cap = 0, partial_off = 0, packdesc_off = 0, mask_off = 0, scal_off = 0;
-    size_t lpart_off = 0, fpart_off = 0, counter_off = 0, fftws_off = 0, tailw_off = 0;
+    size_t lpart_off = 0, fpart_off = 0, counter_off = 0, fftws_off = 0, tailw_off = 0, skinny_off = 0;
     int counter_cursor = 0;
     int loss_blocks = 0, fft_blocks = 0;
     float coefs[8];
@@ -171,6 +171,7 @@ void build_buffers(Plan& pl)
     pl.fftws_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + ssie_fft_workspace_floats(N, B, H, W), 64);   // patches above 128 x 128 only
     pl.mask_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + ((size_t)H * W + 3) / 4, 64);
     pl.tailw_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 3 * 9 * 64 + 16, 64);     // composite weights of the fused tail
+    pl.skinny_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + ssie_skinny_wgrad_ws_floats(), 64);   // final_conv weight-gradient partials
     pl.counter_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 1024, 64);      // tile-queue counters, one per conv launch
     pl.packdesc_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 384 * sizeof(PackDesc) / 4, 64);
     pl.pack_off = pl.ws_floats;     // packed weights grow from here at bind time (size known after a dry build)
@@ -376,6 +377,8 @@ struct Builder {
 
 #define CK(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
 
+int g_skinny_final = 1;  // ssie_debug_set_skinny_final: 0 = final_conv (64 -> 1) on the MFMA tile kernels like every other layer
+
 int build_decomposition_fwd(Builder& b, std::vector<Fn>& ops, const char* xin, int p)
 {
     Plan& pl = b.pl;
@@ -446,7 +449,15 @@ int build_illum_fwd(Builder& b, std::vector<Fn>& ops, bool fused_tail = false)
     CK(b.conv(ops, layer(pl, i + "deconv3.0"), {b.src("d2", 64, H, W)}, H, W, 1, "d3", ACT_RELU, "a0", "u3"));
     if (fused_tail) { push_tail(b, ops); return 0; }
     CK(b.conv(ops, layer(pl, i + "feature_fusion.0"), {b.src("d1", 64, H, W), b.src("d2", 64, H, W), b.src("d3", 64, H, W)}, H, W, 1, "f", ACT_NONE));
-    CK(b.conv(ops, layer(pl, i + "final_conv"), {b.src("f", 64, H, W)}, H, W, 1, "D", ACT_NONE));
+    if (b.h16 || !g_skinny_final) {
+        CK(b.conv(ops, layer(pl, i + "final_conv"), {b.src("f", 64, H, W)}, H, W, 1, "D", ACT_NONE));
+    } else if (!b.dry) {       // 1-channel output: HBM-bound VALU kernel instead of a 32-wide MFMA tile (tail_kernels.hip)
+        const LayerP Lf = layer(pl, i + "final_conv");
+        const float* fp = pl.buf("f"); const float* w = pl.P + Lf.w; const float* bi = pl.P + Lf.b; float* D = pl.buf("D");
+        const int N = pl.N;
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_skinny_fwd(fp, w, bi, D, 4, N, H, W, st); }, K_ELEMENTWISE,
+                         2.0 * N * H * W * 64.0 * 9, "final_conv fwd (VALU)"));
+    }
     if (!b.dry) {
         const float* RL = pl.buf("RL_1"); const float* D = pl.buf("D"); float* S = pl.buf("S");
         const int rl = pl.CRL, cx = pl.CX, B = pl.B; const long npix = (long)pl.N * H * W;
@@ -533,8 +544,17 @@ int build_illum_bwd(Builder& b, std::vector<Fn>& ops)
                  Lff1 = layer(pl, i + "attn.ff_linear1"), Lq = layer(pl, i + "attn.q_linear"), Lk = layer(pl, i + "attn.k_linear"),
                  Lv = layer(pl, i + "attn.v_linear"), Lc3 = layer(pl, i + "conv3.0"), Lc2 = layer(pl, i + "conv2.0"),
                  Lc1 = layer(pl, i + "conv1.0"), Lc0 = layer(pl, i + "conv0.0");
-    CK(b.wgrad(ops, Lf, 1, b.src("f", 64, H, W), 64, H, W, 0, "gD", 0, true));
-    CK(b.dgrad(ops, Lf, 1, "gD", 0, 0, 64, "Gf", nullptr, 0, 0));
+    if (!g_skinny_final) {
+        CK(b.wgrad(ops, Lf, 1, b.src("f", 64, H, W), 64, H, W, 0, "gD", 0, true));
+        CK(b.dgrad(ops, Lf, 1, "gD", 0, 0, 64, "Gf", nullptr, 0, 0));
+    } else if (!b.dry) {
+        const float* fp = pl.buf("f"); const float* gD = pl.buf("gD"); float* Gf = pl.buf("Gf"); const float* w = pl.P + Lf.w;
+        float* part = pl.ws + pl.skinny_off; float* dw = pl.G + Lf.w; float* db = pl.G + Lf.b;
+        const int N = pl.N;
+        const double fl = 2.0 * N * H * W * 64.0 * 9;
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_skinny_wgrad(fp, gD, 4, part, dw, db, N, H, W, st); }, K_ELEMENTWISE, fl, "final_conv wgrad (VALU)"));
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_skinny_dgrad(gD, 4, w, Gf, N, H, W, st); }, K_ELEMENTWISE, fl, "final_conv dgrad (VALU)"));
+    }
     CK(b.wgrad(ops, Lu, 1, b.src("d1", 64, H, W), 64, H, W, 0, "Gf"));
     CK(b.wgrad(ops, Lu, 1, b.src("d2", 64, H, W), 64, H, W, 64, "Gf"));
     CK(b.wgrad(ops, Lu, 1, b.src("d3", 64, H, W), 64, H, W, 128, "Gf", 0, true));
@@ -724,6 +744,7 @@ extern "C" void* ssie_plan_create(int N, int bands, int H, int W, const float* c
 }
 
 extern "C" void ssie_debug_set_overlap(int on) { g_overlap = on; }
+extern "C" void ssie_debug_set_skinny_final(int on) { g_skinny_final = on; }   // takes effect for plans created afterwards
 extern "C" void ssie_debug_set_fused_tail(int on) { g_fused_tail = on; }     // takes effect for plans bound afterwards
 extern "C" void ssie_plan_destroy(void* h) { delete (Plan*)h; }
 extern "C" size_t ssie_plan_workspace_bytes(void* h) { return h ? ((Plan*)h)->ws_floats * 4 : 0; }

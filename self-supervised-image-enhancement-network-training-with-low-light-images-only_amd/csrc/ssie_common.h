@@ -93,6 +93,7 @@ struct WgradParams {
     int nslices, tiles_total, tiles_y, tiles_x, th;
     int ci_blocks, co_blocks, tap_groups;
     int wsplit;             // waves sharing one (ci,co) tile pair = partial slabs written per workgroup (4 / tile pairs)
+    int rows2;              // 9 x 9 only: tap_groups counts PAIRS of kernel rows, one wave pair per row (conv_wgrad_kernel SW = 4)
 };
 
 struct PackDesc {

@@ -187,3 +187,153 @@ int ssie_launch_tail(const void* d1, const void* d2, const void* d3, int bf16_in
     else hipLaunchKernelGGL(tail_kernel<false>, dim3(tiles), dim3(256), 0, st, p);
     return hipGetLastError() == hipSuccess ? 0 : 83;
 }
+
+// ---------------------------------------------------------------------------------------------
+// final_conv (3x3, 64 -> 1, model.py:141,174) in the TRAINING step: forward, data gradient and weight gradient as HBM-bound
+// VALU kernels.  On the 32/64-wide MFMA tiles a 1-channel output (or 1-channel contraction) wastes 31/32 of every MFMA: the
+// three launches took 0.47 ms of a 28 ms step at 3-6 TFLOP/s; their floor is one pass over the 64-channel tensor each.
+// ---------------------------------------------------------------------------------------------
+// forward: D[p] = b + sum_tap w[tap] . f[p + tap].  Phase 1: nine dots per INPUT pixel of the 18 x 18 halo tile (16 lanes per
+// pixel, one float4 each); phase 2: an output pixel sums nine of them.
+__global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict__ f, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         float* __restrict__ D, int d_cs, int N, int H, int W)
+{
+    __shared__ __attribute__((aligned(16))) float ws[9 * 64];
+    __shared__ float T[R3 * R3 * 9];
+    const int tid = threadIdx.x;
+    const int tiles_x = (W + TT - 1) / TT, tiles_y = (H + TT - 1) / TT;
+    const int n = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x % (tiles_x * tiles_y);
+    const int y0 = (tr / tiles_x) * TT, x0 = (tr % tiles_x) * TT;
+    for (int i = tid; i < 9 * 64; i += 256) ws[i] = w[(i & 63) * 9 + (i >> 6)];       // OIHW (1, 64, 3, 3) -> [tap][c]
+    __syncthreads();
+    const int sub = tid & 15, slot = tid >> 4;
+    f32x4 wr[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wr[t] = *(const f32x4*)(ws + t * 64 + sub * 4);
+    for (int it = slot; it < ((R3 * R3 + 15) & ~15); it += 16) {
+        float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int yy = y0 - 1 + it / R3, xx = x0 - 1 + it % R3;
+        if (it < R3 * R3 && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            const f32x4 v = *(const f32x4*)(f + (((size_t)n * H + yy) * W + xx) * 64 + sub * 4);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = v[0] * wr[t][0] + v[1] * wr[t][1] + v[2] * wr[t][2] + v[3] * wr[t][3];
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { float a = acc[t]; a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); a += __shfl_xor(a, 8); acc[t] = a; }
+        if (it < R3 * R3) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) if (sub == t) T[it * 9 + t] = acc[t];
+        }
+    }
+    __syncthreads();
+    const int ty = tid >> 4, tx = tid & 15, y = y0 + ty, x = x0 + tx;
+    if (y < H && x < W) {
+        float d = bias ? bias[0] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int qy = ty + t / 3, qx = tx + t % 3;                      // halo-tile coordinates of p + tap
+            d += T[(qy * R3 + qx) * 9 + t];                                    // outside the image: T = 0 (zero padding)
+        }
+        D[(((size_t)n * H + y) * W + x) * d_cs] = d;
+    }
+}
+
+// data gradient: Gf[q][c] = sum_tap w[tap][c] * gD[q - tap]   (16 lanes per pixel, one float4 of channels each)
+__global__ __launch_bounds__(256) void skinny_dgrad_kernel(const float* __restrict__ gD, int d_cs, const float* __restrict__ w,
+                                                           float* __restrict__ Gf, int N, int H, int W)
+{
+    const int sub = threadIdx.x & 15;
+    f32x4 wr[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wr[t][j] = w[(sub * 4 + j) * 9 + t];
+    const long npix = (long)N * H * W;
+    for (long pix = (long)blockIdx.x * 16 + (threadIdx.x >> 4); pix < npix; pix += (long)gridDim.x * 16) {
+        const int x = (int)(pix % W), y = (int)((pix / W) % H);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int py = y - (t / 3 - 1), px = x - (t % 3 - 1);              // output position p with p + tap = q
+            if (py < 0 || py >= H || px < 0 || px >= W) continue;
+            const float g = gD[(pix + (long)(py - y) * W + (px - x)) * d_cs];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] += g * wr[t][j];
+        }
+        *(f32x4*)(Gf + pix * 64 + sub * 4) = a;
+    }
+}
+
+// weight + bias gradient: dw[c][tap] = sum_p gD[p] * f[p + tap][c] = sum_q f[q][c] * gD[q - tap], db = sum_p gD[p].
+// Every block reduces its grid-stride share of the pixels to one [9][64] (+1) partial (fixed order: bit-reproducible);
+// skinny_wgrad_final_kernel adds the partials in block order into the parameter-gradient buffer.
+#define SKINNY_WGRAD_BLOCKS 1024      // 4 resident blocks per CU: the loop is a chain of dependent loads, so memory-level parallelism comes from occupancy
+__global__ __launch_bounds__(256) void skinny_wgrad_kernel(const float* __restrict__ f, const float* __restrict__ gD, int d_cs,
+                                                           float* __restrict__ part, int N, int H, int W)
+{
+    __shared__ float red[16][9 * 64 + 1];
+    const int sub = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    f32x4 acc[9];
+    float accb = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const long npix = (long)N * H * W;
+    for (long pix = (long)blockIdx.x * 16 + slot; pix < npix; pix += (long)gridDim.x * 16) {
+        const int x = (int)(pix % W), y = (int)((pix / W) % H);
+        const f32x4 v = *(const f32x4*)(f + pix * 64 + sub * 4);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int py = y - (t / 3 - 1), px = x - (t % 3 - 1);
+            if (py < 0 || py >= H || px < 0 || px >= W) continue;
+            const float g = gD[(pix + (long)(py - y) * W + (px - x)) * d_cs];
+            acc[t] += v * g;
+            if (t == 4 && sub == 0) accb += g;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[slot][t * 64 + sub * 4 + j] = acc[t][j];
+    if (sub == 0) red[slot][9 * 64] = accb;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 9 * 64 + 1; i += 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][i];
+        part[(size_t)i * SKINNY_WGRAD_BLOCKS + blockIdx.x] = s;              // [output][block]: the final pass reads rows
+    }
+}
+
+// one wave per output element: lanes stride over the blocks' partials (coalesced), fixed-order butterfly => deterministic
+__global__ __launch_bounds__(256) void skinny_wgrad_final_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dw, float* __restrict__ db)
+{
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i > 9 * 64) return;
+    float s = 0.f;
+    for (int b = lane; b < nblk; b += 64) s += part[(size_t)i * nblk + b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane != 0) return;
+    if (i == 9 * 64) { if (db) db[0] += s; }
+    else dw[(i & 63) * 9 + (i >> 6)] += s;                                   // [tap][c] -> OIHW (1, 64, 3, 3)
+}
+
+int ssie_launch_skinny_fwd(const float* f, const float* w, const float* bias, float* D, int d_cs, int N, int H, int W, hipStream_t st)
+{
+    const int tiles = N * ((H + TT - 1) / TT) * ((W + TT - 1) / TT);
+    hipLaunchKernelGGL(skinny_fwd_kernel, dim3(tiles), dim3(256), 0, st, f, w, bias, D, d_cs, N, H, W);
+    return hipGetLastError() == hipSuccess ? 0 : 84;
+}
+int ssie_launch_skinny_dgrad(const float* gD, int d_cs, const float* w, float* Gf, int N, int H, int W, hipStream_t st)
+{
+    long blocks = ((long)N * H * W + 15) / 16; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(skinny_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, gD, d_cs, w, Gf, N, H, W);
+    return hipGetLastError() == hipSuccess ? 0 : 85;
+}
+size_t ssie_skinny_wgrad_ws_floats() { return (size_t)SKINNY_WGRAD_BLOCKS * (9 * 64 + 1); }
+int ssie_launch_skinny_wgrad(const float* f, const float* gD, int d_cs, float* part, float* dw, float* db, int N, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL(skinny_wgrad_kernel, dim3(SKINNY_WGRAD_BLOCKS), dim3(256), 0, st, f, gD, d_cs, part, N, H, W);
+    hipLaunchKernelGGL(skinny_wgrad_final_kernel, dim3((9 * 64 + 1 + 3) / 4), dim3(256), 0, st, (const float*)part, SKINNY_WGRAD_BLOCKS, dw, db);
+    return hipGetLastError() == hipSuccess ? 0 : 86;
+}

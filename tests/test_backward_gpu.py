@@ -147,7 +147,9 @@ def forced_kernels(pkg, request):
         L.ssie_debug_set_fprop_min_tiles16(0)
         L.ssie_debug_set_fprop_wide_min_tiles(1)
         L.ssie_debug_set_fprop_v2_split_min_tiles(1)
+        L.ssie_debug_set_skinny_final(0)          # and final_conv (64 -> 1) on the MFMA tiles instead of the VALU kernels
     yield request.param
+    L.ssie_debug_set_skinny_final(1)
     L.ssie_debug_set_fprop_min_tiles16(256)
     L.ssie_debug_set_fprop_wide_min_tiles(512)
     L.ssie_debug_set_fprop_v2_split_min_tiles(1024)

@@ -74,3 +74,30 @@ def test_bf16_unsupported_band_count_fails_loudly(H):
     x = O.synthetic_patches(1, 9, 16, 16)
     with pytest.raises(H.SsieError):
         plan.enhance_fwd(x.cuda(), bf16=True)
+
+
+def test_full_resolution_1024_whole_image(H):
+    """BASELINE.json configs[4] at its real size: one 1 x 31 x 1024 x 1024 cube, whole image in one pass - the global attention
+    (model.py:99-119) then runs over 16 384 tokens (4 key-split waves per 32-query workgroup merged through LDS), a size no
+    patch test reaches.  Oracle = the fp32 CPU restatement (4.3 GB of logits); fp32 HIP path at the fp32 bar, bf16 path at the
+    bf16 bar of this file."""
+    n, bands, hw = 1, 31, 1024
+    plan, P = _plan(H, n, bands, hw, hw)
+    x = O.synthetic_patches(n, bands, hw, hw)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    with torch.no_grad():
+        R, I, D, S = O.enhance_forward(P, x)
+    ref = dict(R=R, I=I, D=D, S=S)
+    B = bands
+    for mode, tol, min_psnr in (("f32", 2e-5, 100.0), ("bf16", 5e-3, 60.0)):
+        plan.enhance_fwd(x.cuda(), bf16=(mode == "bf16"))
+        torch.cuda.synchronize()
+        got = dict(R=plan.nchw("RL_1", 0, B), I=plan.nchw("RL_1", B, B + 1), D=plan.nchw("D", 0, 1), S=plan.nchw("S", 0, B))
+        for k in got:
+            g = got[k].cpu()
+            assert torch.isfinite(g).all(), (mode, k)
+            err = (g - ref[k]).abs().max().item()
+            psnr = O.psnr(g, ref[k])
+            print(f"[1024x1024 {mode}] {k}: max abs {err:.2e}  PSNR {psnr:.1f} dB")
+            assert err <= tol, (mode, k, err)
+            assert psnr >= min_psnr, (mode, k, psnr)

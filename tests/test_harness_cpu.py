@@ -33,6 +33,26 @@ def test_config_priority_cli_over_yaml_over_default(tmp_path, monkeypatch):
         m.parse_args(["--config", str(cfg), "--phase", "test"])
 
 
+def test_presets_cover_the_reference_config_files():
+    """config/presets.yml + --preset reproduce the key sets of the reference's eight config/*.yml (values checked for the keys
+    that differ between them: coefficients, sensor range, batch, LR schedule, fold paths)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ssie_main", os.path.join(ROOT, "main.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    pre = os.path.join(ROOT, "config", "presets.yml")
+    a = m.parse_args(["--config", pre, "--phase", "train"])
+    assert a.c_loss_i_smooth_delta == 2000 and a.c_loss_fourier == 20 and a.global_min == 238.0 and a.batch_size == 2
+    assert a.lr_update_factor == 0.1 and a.lr_update_period == 250
+    b = m.parse_args(["--config", pre, "--preset", "indoor_li_et_al_cv4", "--phase", "train"])
+    assert b.c_loss_i_smooth_delta == 20 and b.c_loss_fourier == 0.2 and b.batch_size == 1 and b.save_i_delta is True
+    assert abs(b.global_max - 1.6697606) < 1e-9 and b.lr_update_factor == 1 and b.lr_update_period == 400
+    assert b.train_data.endswith("train_fold_4/low") and b.label_dir.endswith("test_fold_4/high")
+    c = m.parse_args(["--config", pre, "--preset", "indoor_jyu", "--batch_size", "8", "--phase", "train"])
+    assert "jyu_indoor" in c.test_data and c.batch_size == 8 and c.c_loss_fourier == 20
+    with pytest.raises(SystemExit):
+        m.parse_args(["--config", pre, "--preset", "nope", "--phase", "train"])
+
+
 def test_load_hsi_double_normalisation_and_roundtrip(pkg, tmp_path):
     harness, _ = pkg
     rng = np.random.RandomState(0)
