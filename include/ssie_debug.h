@@ -36,6 +36,7 @@ void ssie_debug_set_fprop_v2_split(int on);             /* [1] 0 = one 8-wave wo
 void ssie_debug_set_fprop_v2_split_min_tiles(int v);    /* [1024] */
 void ssie_debug_set_fprop_wgs_per_cu(int v);
 void ssie_debug_set_fused_tail(int on);                 /* [1] 0 = inference keeps feature_fusion / final_conv / compose as separate launches (plans bound afterwards) */
+void ssie_debug_set_spectral9(int on);                  /* [1] 0 = the 9 x 9 convolution (shallow_conv) on the direct MFMA kernels instead of the frequency domain (plans created afterwards) */
 void ssie_debug_set_skinny_final(int on);               /* [1] 0 = final_conv (64 -> 1) forward / gradients on the MFMA tile kernels (plans created afterwards) */
 void ssie_debug_set_loss_generic(int v);                 /* [0] 1 = the half-wave-per-pixel loss kernel instead of the tiled one */
 void ssie_debug_set_wgrad_sliding(int v);

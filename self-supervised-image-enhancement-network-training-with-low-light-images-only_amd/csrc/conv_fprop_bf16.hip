@@ -274,21 +274,63 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16_kernel(const ConvParam
 
             const f32x4* As = As0 + a_cur * HP4;
             const f32x4* Bs = Bs0 + buf * BSZ;
-            for (int tl = 0; tl < tg; ++tl) {
-                const int off = tapoff[t0 + tl];
-#pragma unroll
-                for (int sc = 0; sc < 2; ++sc) {
-                    const f32x4 bf = Bs[(tl * 4 + sc * 2 + h) * BN + wn * 32 + li];
-                    f32x4 af[MT];
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        const int hp = pixbase[m] + off;
-                        af[m] = As[hp * 4 + ((sc * 2 + h) ^ ssie_swz(hp))];
-                    }
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) acc[m] = MFMA_BF16(bf, af[m], acc[m]);
-                }
+            // Tap loop with a COMPILE-TIME trip count (groups are 9, 4, 2 or 1 taps): the A-fragment byte addresses of the
+            // group are computed once per step (k-half 1 = the same address ^ 32) and the fragments of tap t+1 / k-half 1 are
+            // in flight under the MFMAs before them.  The rolled loop recomputed the swizzled address per fragment (~7 VALU
+            // per 128-bit read) and issued each read right before its use: the 81-tap layer ran its MFMA pipe at 29 %.
+            const char* Ab = (const char*)As;
+            const f32x4* Bl = Bs + h * BN + wn * 32 + li;
+#define G_LD(BF, AF, TL, SC)                                                                              \
+            {                                                                                             \
+                BF = Bl[((TL) * 4 + (SC) * 2) * BN];                                                      \
+                _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_) AF[m_] = *(const f32x4*)(Ab + ((SC) ? (ad[TL][m_] ^ 32) : ad[TL][m_])); \
             }
+#define G_MFMA(BF, AF) _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_) acc[m_] = MFMA_BF16(BF, AF[m_], acc[m_]);
+#define G_TAPS(TG_)                                                                                       \
+            {                                                                                             \
+                int ad[TG_][MT];                                                                          \
+                _Pragma("unroll") for (int tl = 0; tl < TG_; ++tl) {                                      \
+                    const int off_ = tapoff[t0 + tl];                                                     \
+                    _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_) {                                   \
+                        const int hp_ = pixbase[m_] + off_;                                               \
+                        ad[tl][m_] = (hp_ * 4 + (h ^ ssie_swz(hp_))) * 16;                                \
+                    }                                                                                     \
+                }                                                                                         \
+                f32x4 bX, bY, aX[MT], aY[MT];                                                             \
+                G_LD(bX, aX, 0, 0)                                                                        \
+                _Pragma("unroll") for (int tl = 0; tl < TG_; ++tl) {                                      \
+                    G_LD(bY, aY, tl, 1)                                                                   \
+                    G_MFMA(bX, aX)                                                                        \
+                    if (tl + 1 < TG_) G_LD(bX, aX, (tl + 1 < TG_ ? tl + 1 : 0), 0)                         \
+                    G_MFMA(bY, aY)                                                                        \
+                }                                                                                         \
+            }
+            switch (tg) {
+            case 9: G_TAPS(9) break;
+            case 4: G_TAPS(4) break;
+            case 2: G_TAPS(2) break;
+            case 1: G_TAPS(1) break;
+            default:
+                for (int tl = 0; tl < tg; ++tl) {
+                    const int off = tapoff[t0 + tl];
+#pragma unroll
+                    for (int sc = 0; sc < 2; ++sc) {
+                        const f32x4 bf = Bs[(tl * 4 + sc * 2 + h) * BN + wn * 32 + li];
+                        f32x4 af[MT];
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            const int hp = pixbase[m] + off;
+                            af[m] = As[hp * 4 + ((sc * 2 + h) ^ ssie_swz(hp))];
+                        }
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) acc[m] = MFMA_BF16(bf, af[m], acc[m]);
+                    }
+                }
+                break;
+            }
+#undef G_TAPS
+#undef G_MFMA
+#undef G_LD
             if (tid == 0 && step == 0 && nsteps > 1 && p.tile_counter)
                 fetched = (int)gridDim.x + atomicAdd(p.tile_counter, 1);
             chunk = nchunk; g = ng; a_cur = a_nxt;
@@ -601,8 +643,8 @@ static size_t lds_bytes_h(const ConvParams& p, int nt)
 template <int NT, int NA2, int TH>
 static int launch_h_t(const ConvParams& p, size_t lds, hipStream_t st)
 {
-    static bool set = false;
-    if (!set) { hipFuncSetAttribute((const void*)conv_fprop_bf16_kernel<NT, NA2, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    static unsigned seen = 0;
+    ssie_allow_full_lds((const void*)conv_fprop_bf16_kernel<NT, NA2, TH>, seen);
     const size_t tiles = (size_t)p.N * p.tiles_y * p.tiles_x * p.co_blocks;
     const size_t wgs = tiles < 256 ? tiles : 256;
     hipLaunchKernelGGL((conv_fprop_bf16_kernel<NT, NA2, TH>), dim3((unsigned)wgs), dim3(512), lds, st, p);
@@ -623,12 +665,9 @@ int ssie_launch_fprop_bf16(const ConvParams& p_in, hipStream_t st)
     const size_t lds = lds_bytes_h(p, nt);
     if (na2 > 5 || lds > 160 * 1024) return 62;
     if (p.tw == 32) {                      // geometry built for the wide kernel (ssie_make_conv_bf16)
-        static bool set = false;
-        if (!set) {
-            hipFuncSetAttribute((const void*)conv_fprop_bf16w_kernel<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute((const void*)conv_fprop_bf16w_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            set = true;
-        }
+        static unsigned seen_a = 0, seen_b = 0;
+        ssie_allow_full_lds((const void*)conv_fprop_bf16w_kernel<5, false>, seen_a);
+        ssie_allow_full_lds((const void*)conv_fprop_bf16w_kernel<5, true>, seen_b);
         const size_t tiles = (size_t)p.N * p.tiles_y * p.tiles_x * p.co_blocks;
         const dim3 grid((unsigned)(tiles < 256 ? tiles : 256));
 #ifdef SSIE_STAMP

@@ -519,8 +519,8 @@ extern "C" void ssie_debug_set_fprop_v2_split_min_tiles(int v) { g_v2_split_min_
 template <int NT, int NA2, int NW, int TH = 16>
 static int launch_v2_t(const ConvParams& p, size_t lds, hipStream_t st)
 {
-    static bool set = false;
-    if (!set) { hipFuncSetAttribute((const void*)conv_fprop_v2_kernel<NT, NA2, NW, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    static unsigned seen = 0;
+    ssie_allow_full_lds((const void*)conv_fprop_v2_kernel<NT, NA2, NW, TH>, seen);
     const size_t tiles = (size_t)p.N * p.tiles_y * p.tiles_x * p.co_blocks;
     const size_t cap = NW == 8 ? 256 : 512;
     const size_t wgs = tiles < cap ? tiles : cap;
@@ -533,12 +533,9 @@ int ssie_launch_fprop_v2(const ConvParams& p, hipStream_t st)
     const int nt = (p.Cout_pad % 64 == 0) ? 2 : 1;
     if (p.tw == 32) {      // geometry built for the wide kernel (ssie_make_conv)
         const size_t lds = ssie_fprop_v2_lds_bytes(p, 2);
-        static bool set = false;
-        if (!set) {
-            hipFuncSetAttribute((const void*)conv_fprop_v2w_kernel<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute((const void*)conv_fprop_v2w_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            set = true;
-        }
+        static unsigned seen_a = 0, seen_b = 0;
+        ssie_allow_full_lds((const void*)conv_fprop_v2w_kernel<5, false>, seen_a);
+        ssie_allow_full_lds((const void*)conv_fprop_v2w_kernel<5, true>, seen_b);
         const size_t tiles = (size_t)p.N * p.tiles_y * p.tiles_x * p.co_blocks;
         const dim3 grid((unsigned)(tiles < 256 ? tiles : 256));
         if (p.nsrc == 1) hipLaunchKernelGGL((conv_fprop_v2w_kernel<5, true>), grid, dim3(512), lds, st, p);

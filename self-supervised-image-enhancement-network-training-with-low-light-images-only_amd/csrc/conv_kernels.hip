@@ -738,8 +738,8 @@ extern "C" void ssie_debug_set_fprop_wgs_per_cu(int v) { ssie_fprop_wgs_per_cu =
 template <int NT, int NA, int TH>
 static int launch_fprop_t(const ConvParams& p, size_t lds, hipStream_t st)
 {
-    static bool set = false;
-    if (!set) { hipFuncSetAttribute((const void*)conv_fprop_kernel<NT, NA, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    static unsigned seen = 0;
+    ssie_allow_full_lds((const void*)conv_fprop_kernel<NT, NA, TH>, seen);
     const size_t tiles = (size_t)p.N * p.tiles_y * p.tiles_x * p.co_blocks;
     const int per_cu = (int)((160 * 1024) / lds);
     size_t wgs = (size_t)256 * (per_cu < 1 ? 1 : (per_cu > ssie_fprop_wgs_per_cu ? ssie_fprop_wgs_per_cu : per_cu));
@@ -797,8 +797,8 @@ static int launch_wgrad_t(const WgradParams& p, hipStream_t st)
         if (lds < red) lds = red;
     }
     if (lds > 160 * 1024) return 23;
-    static bool set = false;
-    if (!set) { hipFuncSetAttribute((const void*)conv_wgrad_kernel<CI, CO, NU, SW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    static unsigned seen = 0;
+    ssie_allow_full_lds((const void*)conv_wgrad_kernel<CI, CO, NU, SW>, seen);
     dim3 grid(p.nslices, p.ci_blocks * p.co_blocks, p.tap_groups);      // SW = 4: tap_groups = pairs of kernel rows
     hipLaunchKernelGGL((conv_wgrad_kernel<CI, CO, NU, SW>), grid, dim3(256), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : 24;

@@ -10,6 +10,7 @@
 #include "layer_ops.h"
 #include "loss_kernels.h"
 #include "attention.h"
+#include "spectral_conv.h"
 #include "../../include/ssie_hip.h"
 #include <functional>
 #include <map>
@@ -23,7 +24,7 @@ namespace {
 
 typedef std::function<int(hipStream_t)> FnT;
 // op kinds for per-kernel-class profiling (bench.py roofline): see ssie_plan_profile_step
-enum { K_FPROP2 = 0, K_FPROP1, K_WGRAD, K_WGRAD_REDUCE, K_COLSUM, K_PACK, K_LOSS, K_FFT, K_ATTN, K_ELEMENTWISE, K_NKINDS };
+enum { K_FPROP2 = 0, K_FPROP1, K_WGRAD, K_WGRAD_REDUCE, K_COLSUM, K_PACK, K_LOSS, K_FFT, K_ATTN, K_ELEMENTWISE, K_SPEC, K_NKINDS };
 struct Fn {
     FnT fn; int kind; double flops; std::string tag;
     int slab = 0;       // K_WGRAD / K_WGRAD_REDUCE: which of the two slab areas the launch writes / reads
@@ -37,6 +38,7 @@ struct LayerP { size_t w, b; int cout, cin, k; bool transposed; };
 
 const int CH = 64;
 const int kWgs = 512;
+int g_spectral9 = 1;     // ssie_debug_set_spectral9: 0 = the 9 x 9 convolution on the direct MFMA kernels (plans created afterwards)
 
 struct Plan {
     int N, B, H, W, CX, CRL;
@@ -47,6 +49,9 @@ struct Plan {
     size_t ws_floats = 0;
     size_t slab_off = 0, slab_off2 = 0, slab_cap = 0, partial_off = 0, packdesc_off = 0, mask_off = 0, scal_off = 0;
     size_t lpart_off = 0, fpart_off = 0, counter_off = 0, fftws_off = 0, tailw_off = 0, skinny_off = 0;
+    // frequency-domain 9 x 9 convolution (spectral_conv.hip): tiles per pass, padded band count, buffers (float offsets)
+    bool spectral = false; int sp_Mt = 0, sp_Kp = 0, sp_slices = 8;
+    size_t sp_Xf = 0, sp_Yf = 0, sp_Zf = 0, sp_Gn = 0, sp_Bf = 0, sp_Bd = 0, sp_dW = 0;
     int counter_cursor = 0;
     int loss_blocks = 0, fft_blocks = 0;
     float coefs[8];
@@ -171,6 +176,16 @@ void build_buffers(Plan& pl)
     pl.fftws_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + ssie_fft_workspace_floats(N, B, H, W), 64);   // patches above 128 x 128 only
     pl.mask_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + ((size_t)H * W + 3) / 4, 64);
     pl.tailw_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 3 * 9 * 64 + 16, 64);     // composite weights of the fused tail
+    {   // spectral 9 x 9: X^ of both passes [f][2 Mt][Kp], Y^ / halo-G^ [f][Mt][64], Z^ [f][Mt][Kp], no-halo G^ [f][2 Mt][64], weights, dW^ slices
+        int ty, tx; pl.sp_Mt = N * ssie_spec_tiles(H, W, &ty, &tx); pl.sp_Kp = pl.CX;
+        pl.spectral = g_spectral9 && pl.CX % 32 == 0;
+        if (pl.spectral) {
+            const size_t nf = SSIE_SPEC_NF, Mt = pl.sp_Mt, Kp = pl.sp_Kp;
+            auto take = [&](size_t complexes) { const size_t o = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 2 * complexes, 64); return o; };
+            pl.sp_Xf = take(nf * 2 * Mt * Kp); pl.sp_Yf = take(nf * Mt * 64); pl.sp_Zf = take(nf * Mt * Kp); pl.sp_Gn = take(nf * 2 * Mt * 64);
+            pl.sp_Bf = take(nf * Kp * 64); pl.sp_Bd = take(nf * 64 * Kp); pl.sp_dW = take(((size_t)pl.sp_slices * nf + 9 * SSIE_SPEC_KX) * Kp * 64);
+        }
+    }
     pl.skinny_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + ssie_skinny_wgrad_ws_floats(), 64);   // final_conv weight-gradient partials
     pl.counter_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 1024, 64);      // tile-queue counters, one per conv launch
     pl.packdesc_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 384 * sizeof(PackDesc) / 4, 64);
@@ -365,6 +380,46 @@ struct Builder {
         ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_mask_axpy(sp, scs, yp, ycs, mode, dp, dcs, npix, C, accumulate, st); }, K_ELEMENTWISE, 0.0, std::string("mask_axpy ") + src + "->" + dst));
     }
 
+    // ---- frequency-domain 9 x 9 convolution (shallow_conv), spectral_conv.hip ----
+    float2* spc(size_t off) { return dry ? nullptr : (float2*)(pl.ws + off); }
+    // forward: xin (x or S) -> out (sh_1 / sh_2); pass = 1 also transforms the weights
+    void spec_fwd(std::vector<Fn>& ops, const LayerP& L, const char* xin, int pass, const char* out)
+    {
+        if (dry) return;
+        const int N = pl.N, H = pl.H, W = pl.W, Mt = pl.sp_Mt, Kp = pl.sp_Kp, cx = pl.CX, B = pl.B, m0 = pass == 1 ? 0 : Mt;
+        float2* Xf = spc(pl.sp_Xf); float2* Yf = spc(pl.sp_Yf); float2* Bf = spc(pl.sp_Bf); float2* Bd = spc(pl.sp_Bd);
+        const float* w = pl.P + L.w; const float* bias = pl.P + L.b; const float* xp = pl.buf(xin); float* op = pl.buf(out);
+        const int ocs = pl.bi(out).cs;
+        if (pass == 1) ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_spec_weights(w, 64, B, Kp, 64, Bf, Bd, st); }, K_SPEC, 0.0, "spectral 9x9: weights"));
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_spec_fft(xp, cx, Kp, N, H, W, 1, Xf, m0, 2 * Mt, st); }, K_SPEC, 0.0, "spectral 9x9: fft in"));
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_spec_gemm(Xf, 2 * Mt, m0, Bf, Yf, Mt, 0, Mt, Kp, 64, st); }, K_SPEC,
+                         2.0 * N * H * W * 64.0 * B * 81, "spectral 9x9: fwd gemm"));
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_spec_ifft(Yf, 0, Mt, 64, N, H, W, op, ocs, 64, bias, 0, st); }, K_SPEC, 0.0, "spectral 9x9: ifft out"));
+    }
+    // data gradient of pass 2: g (64 ch) -> gx += ...
+    void spec_dgrad(std::vector<Fn>& ops, const char* g, const char* gx)
+    {
+        if (dry) return;
+        const int N = pl.N, H = pl.H, W = pl.W, Mt = pl.sp_Mt, Kp = pl.sp_Kp, B = pl.B;
+        float2* Yf = spc(pl.sp_Yf); float2* Zf = spc(pl.sp_Zf); float2* Bd = spc(pl.sp_Bd);
+        const float* gp = pl.buf(g); float* xp = pl.buf(gx); const int gcs = pl.bi(g).cs, xcs = pl.bi(gx).cs;
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_spec_fft(gp, gcs, 64, N, H, W, 1, Yf, 0, Mt, st); }, K_SPEC, 0.0, "spectral 9x9: fft grad (halo)"));
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_spec_gemm(Yf, Mt, 0, Bd, Zf, Mt, 0, Mt, 64, Kp, st); }, K_SPEC,
+                         2.0 * N * H * W * 64.0 * B * 81, "spectral 9x9: dgrad gemm"));
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_spec_ifft(Zf, 0, Mt, Kp, N, H, W, xp, xcs, B, nullptr, 1, st); }, K_SPEC, 0.0, "spectral 9x9: ifft dgrad"));
+    }
+    // weight gradient over both passes: g = pass-1 half of the [Gsh ; Gsh_2] pair, X^ of x and S still in the workspace
+    void spec_wgrad(std::vector<Fn>& ops, const LayerP& L, const char* g)
+    {
+        if (dry) return;
+        const int N = pl.N, H = pl.H, W = pl.W, Mt = pl.sp_Mt, Kp = pl.sp_Kp, B = pl.B, ns = pl.sp_slices;
+        float2* Xf = spc(pl.sp_Xf); float2* Gn = spc(pl.sp_Gn); float2* dWs = spc(pl.sp_dW);
+        const float* gp = pl.buf(g); const int gcs = pl.bi(g).cs; float* dw = pl.G + L.w;
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_spec_fft(gp, gcs, 64, 2 * N, H, W, 0, Gn, 0, 2 * Mt, st); }, K_SPEC, 0.0, "spectral 9x9: fft grad (tiles)"));
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_spec_wgrad(Xf, Gn, dWs, 2 * Mt, Kp, ns, 64, B, dw, st); }, K_SPEC,
+                         2.0 * 2 * N * H * W * 64.0 * B * 81, "spectral 9x9: wgrad"));
+    }
+
     void upadj(std::vector<Fn>& ops, const char* src, int Hv, int Wv, const char* dst, int accumulate)
     {
         if (dry) return;
@@ -387,7 +442,8 @@ int build_decomposition_fwd(Builder& b, std::vector<Fn>& ops, const char* xin, i
     const std::string c0 = nm("c0"), sh = nm("sh"), c1 = nm("c1"), c2 = nm("c2"), c3 = nm("c3"), dc = nm("dc"), c5 = nm("c5"), c7 = nm("c7"), RL = nm("RL");
     const std::string d = "decomposition_net.";
     CK(b.conv(ops, layer(pl, d + "conv0.0"), {b.src(xin, pl.CX, H, W)}, H, W, 1, c0.c_str(), ACT_RELU));
-    CK(b.conv(ops, layer(pl, d + "shallow_conv.0"), {b.src(xin, pl.CX, H, W)}, H, W, 1, sh.c_str(), ACT_NONE));
+    if (pl.spectral && !b.h16) b.spec_fwd(ops, layer(pl, d + "shallow_conv.0"), xin, p, sh.c_str());
+    else CK(b.conv(ops, layer(pl, d + "shallow_conv.0"), {b.src(xin, pl.CX, H, W)}, H, W, 1, sh.c_str(), ACT_NONE));
     CK(b.conv(ops, layer(pl, d + "conv1.0"), {b.src(sh.c_str(), 64, H, W)}, H, W, 1, c1.c_str(), ACT_RELU));
     CK(b.conv(ops, layer(pl, d + "conv2.0"), {b.src(c1.c_str(), 64, H, W)}, H, W, 2, c2.c_str(), ACT_RELU));
     CK(b.conv(ops, layer(pl, d + "conv3.0"), {b.src(c2.c_str(), 128, H2, W2)}, H2, W2, 1, c3.c_str(), ACT_RELU));
@@ -525,10 +581,12 @@ int build_decomposition_bwd(Builder& b, std::vector<Fn>& ops, const char* xin, i
     CK(b.dgrad(ops, L2, 2, G2.c_str(), 0, 0, 64, G1.c_str(), c1.c_str(), MASK_RELU, 1));
     if (wg) CK(b.wgrad(ops, L1, 1, b.src("sh_1", 64, H, W), 64, H, W, 0, "G1", 0, true, 2));
     CK(b.dgrad(ops, L1, 1, G1.c_str(), 0, 0, 64, Gsh.c_str(), nullptr, 0, 0));
-    if (wg) CK(b.wgrad(ops, Ls, 1, b.src("x", pl.CX, H, W), pl.B, H, W, 0, "Gsh", 0, true, 2));
+    if (wg && pl.spectral) { b.spec_wgrad(ops, Ls, "Gsh"); b.bias_grad(ops, Ls, "Gsh", 0, 2); }
+    else if (wg) CK(b.wgrad(ops, Ls, 1, b.src("x", pl.CX, H, W), pl.B, H, W, 0, "Gsh", 0, true, 2));
     if (wg) CK(b.wgrad(ops, L0, 1, b.src("x", pl.CX, H, W), pl.B, H, W, 0, "G0", 0, true, 2));
     if (input_grad) {
-        CK(b.dgrad(ops, Ls, 1, Gsh.c_str(), 0, 0, pl.B, "gS", nullptr, 0, 1));
+        if (pl.spectral) b.spec_dgrad(ops, Gsh.c_str(), "gS");
+        else CK(b.dgrad(ops, Ls, 1, Gsh.c_str(), 0, 0, pl.B, "gS", nullptr, 0, 1));
         CK(b.dgrad(ops, L0, 1, G0.c_str(), 0, 0, pl.B, "gS", nullptr, 0, 1));
     }
     return 0;
@@ -744,6 +802,7 @@ extern "C" void* ssie_plan_create(int N, int bands, int H, int W, const float* c
 }
 
 extern "C" void ssie_debug_set_overlap(int on) { g_overlap = on; }
+extern "C" void ssie_debug_set_spectral9(int on) { g_spectral9 = on; }
 extern "C" void ssie_debug_set_skinny_final(int on) { g_skinny_final = on; }   // takes effect for plans created afterwards
 extern "C" void ssie_debug_set_fused_tail(int on) { g_fused_tail = on; }     // takes effect for plans bound afterwards
 extern "C" void ssie_plan_destroy(void* h) { delete (Plan*)h; }

@@ -1,0 +1,430 @@
+// The 9 x 9 convolution (`shallow_conv`, /root/reference/model.py:35,52: 34 % of the loss-forward MACs at 31 bands, 70 % at 256)
+// in the FREQUENCY domain: forward, data gradient and weight gradient.
+//
+// A direct 9 x 9 convolution spends 81 MACs per (pixel, input channel, output channel).  With 32 x 32 overlap-save tiles
+// (24 x 24 valid outputs each) the same result costs one complex MAC per (frequency, tile, ci, co) = 4 real MACs per
+// 1.06 valid pixels (544 half-spectrum bins per 576 valid pixels): ~20x fewer FLOPs, and fewer roundings per output - in fp32
+// the spectral result is CLOSER to the fp64 reference than the direct fp32 sum of 2 511 products (2.7e-7 vs 2.4e-6 of the
+// tensor's maximum, measured on the parity fixtures).  The work becomes HBM-bound streaming of spectral tensors:
+//
+//   spec_fft_tiles      x (N,H,W,C) -> X^[f][m][c]      32 x 32 real FFT of every tile window, half spectrum f = ky*17 + kx
+//   spec_weights        w (Co,Ci,9,9) -> B[f][ci][co] = conj(FFT(w padded)), B'[f][co][ci] = conj(FFT(flipped w))
+//   spec_gemm           Y^[f][m][n] = sum_k A[f][m][k] * B[f][k][n]   (complex, per frequency; as a real GEMM on the fp32 MFMA)
+//   spec_ifft_out       Y^ -> y (N,H,W,Co): inverse transform, the 24 x 24 valid block of every tile (+ bias | accumulate)
+//   spec_wgrad_reduce   dW^[s][f][ci][co] = sum_{m in slice s} conj(G^[f][m][co]) * X^[f][m][ci]
+//   spec_wgrad_out      dw[co][ci][dy][dx] += (1/1024) sum_s sum_f Re(dW^ e^{+i theta}) over the 9 x 9 taps only
+//
+// nn.Conv2d is a cross-correlation y[p] = sum_t w[t] x[p + t - 4]; with the tile window starting 4 pixels before the tile,
+// output j of a tile is sum_t w[t] xwin[j + t] = circular correlation (no wrap for j < 24) <-> X^ * conj(W^).  The data
+// gradient is the same correlation with the flipped kernel on windows of the output gradient; the weight gradient is the
+// correlation of the ZERO-PADDED 24 x 24 gradient tile with the input window, of which only lags 0..8 are kept (j + t <= 31:
+// no wrap either).
+#include "spectral_conv.h"
+#include <math.h>
+
+namespace {
+
+constexpr int T = SSIE_SPEC_T, V = SSIE_SPEC_V, KX = SSIE_SPEC_KX, NF = SSIE_SPEC_NF;
+
+// exp(-2 pi i j / 32), j = 0 .. 15 (forward twiddles; the inverse conjugates)
+__device__ __forceinline__ float2 tw32(int j)
+{
+    constexpr float C[16] = {1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f, 0.55557023301960218f,
+                             0.38268343236508977f, 0.19509032201612825f, 0.f, -0.19509032201612825f, -0.38268343236508977f, -0.55557023301960218f,
+                             -0.70710678118654752f, -0.83146961230254524f, -0.92387953251128674f, -0.98078528040323043f};
+    constexpr float S[16] = {0.f, 0.19509032201612825f, 0.38268343236508977f, 0.55557023301960218f, 0.70710678118654752f, 0.83146961230254524f,
+                             0.92387953251128674f, 0.98078528040323043f, 1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f,
+                             0.70710678118654752f, 0.55557023301960218f, 0.38268343236508977f, 0.19509032201612825f};
+    return make_float2(C[j], -S[j]);
+}
+
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// in-register radix-2 DIT FFT of 32 complex values, fully unrolled (every index and twiddle is a compile-time constant)
+template <bool INVERSE>
+__device__ __forceinline__ void fft32(float2 (&v)[32])
+{
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int j = ((i & 1) << 4) | ((i & 2) << 2) | (i & 4) | ((i & 8) >> 2) | ((i & 16) >> 4);
+        if (i < j) { const float2 t = v[i]; v[i] = v[j]; v[j] = t; }
+    }
+#pragma unroll
+    for (int s = 1; s <= 5; ++s) {
+        const int half = 1 << (s - 1), step = 32 >> s;
+#pragma unroll
+        for (int g = 0; g < 32; g += 2 * half)
+#pragma unroll
+            for (int k = 0; k < half; ++k) {
+                float2 w = tw32(k * step);
+                if (INVERSE) w.y = -w.y;
+                const float2 t = cmulf(v[g + k + half], w);
+                const float2 a = v[g + k];
+                v[g + k] = make_float2(a.x + t.x, a.y + t.y);
+                v[g + k + half] = make_float2(a.x - t.x, a.y - t.y);
+            }
+    }
+}
+
+constexpr int CG = 8;                              // channels per workgroup of the tile transforms
+constexpr int RS = T + 1;                          // padded row stride of the real tile in LDS
+
+// ---- x -> X^ ------------------------------------------------------------------------------------------------------------
+// grid (tiles of this tensor, Cp / 8); window origin = (V*a + org, V*b + org); `valid` = 32 for halo windows (org = -4),
+// 24 for the zero-padded gradient tiles of the weight gradient (org = 0)
+__global__ __launch_bounds__(256) void spec_fft_tiles_kernel(const float* __restrict__ in, int cs, int H, int W, int tiles_y, int tiles_x,
+                                                             int org, int valid, float2* __restrict__ out, int m0, int Mtot, int Cp)
+{
+    // the real tile R and the half-complex tile Cx share one buffer (static LDS is limited to 64 KB): a row is pulled into
+    // registers, and only after a barrier written back as its spectrum
+    __shared__ float2 buf[CG * T * KX];
+    float* R = (float*)buf;                        // [CG][T][RS] floats  (33.8 KB of the 34.8 KB)
+    float2* Cx = buf;                              // [CG][T][KX] complex
+    static_assert(CG * T * RS * 4 <= CG * T * KX * 8, "R must fit inside Cx");
+    const int tid = threadIdx.x, mloc = blockIdx.x, c0 = blockIdx.y * CG;
+    const int b = mloc % tiles_x, a = (mloc / tiles_x) % tiles_y, n = mloc / (tiles_x * tiles_y);
+    const int oy = V * a + org, ox = V * b + org;
+    for (int idx = tid; idx < T * T * (CG / 4); idx += 256) {
+        const int q = idx & 1, px = idx >> 1, y = px >> 5, x = px & 31;
+        const int gy = oy + y, gx = ox + x;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (y < valid && x < valid && gy >= 0 && gy < H && gx >= 0 && gx < W && c0 + 4 * q < cs)
+            v = *(const f32x4*)(in + (((size_t)n * H + gy) * W + gx) * cs + c0 + 4 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) R[((4 * q + j) * T + y) * RS + x] = v[j];
+    }
+    __syncthreads();
+    {   // rows: one real row of 32 per thread
+        const int c = tid >> 5, y = tid & 31;
+        float2 v[32];
+#pragma unroll
+        for (int x = 0; x < 32; ++x) v[x] = make_float2(R[(c * T + y) * RS + x], 0.f);
+        fft32<false>(v);
+        __syncthreads();                           // every row of R is in registers: the buffer may now hold spectra
+#pragma unroll
+        for (int kx = 0; kx < KX; ++kx) Cx[(c * T + y) * KX + kx] = v[kx];
+    }
+    __syncthreads();
+    if (tid < CG * KX) {   // columns: one complex column of 32 per thread, in place
+        const int c = tid / KX, kx = tid % KX;
+        float2 v[32];
+#pragma unroll
+        for (int y = 0; y < 32; ++y) v[y] = Cx[(c * T + y) * KX + kx];
+        fft32<false>(v);
+#pragma unroll
+        for (int ky = 0; ky < 32; ++ky) Cx[(c * T + ky) * KX + kx] = v[ky];
+    }
+    __syncthreads();
+    const size_t m = (size_t)m0 + mloc;
+    for (int idx = tid; idx < NF * CG; idx += 256) {
+        const int c = idx & (CG - 1), f = idx >> 3;
+        out[((size_t)f * Mtot + m) * Cp + c0 + c] = Cx[(c * T + f / KX) * KX + f % KX];
+    }
+}
+
+// ---- Y^ -> y ------------------------------------------------------------------------------------------------------------
+// grid (tiles, ceil(Cout_pad / 8)); writes the 24 x 24 valid block of tile m: out = (accumulate ? out : 0) + y + bias
+__global__ __launch_bounds__(256) void spec_ifft_out_kernel(const float2* __restrict__ Yf, int m0, int Mtot, int Np, int H, int W, int tiles_y, int tiles_x,
+                                                            float* __restrict__ out, int cs, int Cout, const float* __restrict__ bias, int accumulate)
+{
+    __shared__ float2 buf[CG * T * KX];            // Cx, then (after a barrier) the real tile R: see spec_fft_tiles_kernel
+    float* R = (float*)buf;
+    float2* Cx = buf;
+    const int tid = threadIdx.x, mloc = blockIdx.x, c0 = blockIdx.y * CG;
+    const int b = mloc % tiles_x, a = (mloc / tiles_x) % tiles_y, n = mloc / (tiles_x * tiles_y);
+    const size_t m = (size_t)m0 + mloc;
+    for (int idx = tid; idx < NF * CG; idx += 256) {
+        const int c = idx & (CG - 1), f = idx >> 3;
+        Cx[(c * T + f / KX) * KX + f % KX] = (c0 + c < Np) ? Yf[((size_t)f * Mtot + m) * Np + c0 + c] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    if (tid < CG * KX) {
+        const int c = tid / KX, kx = tid % KX;
+        float2 v[32];
+#pragma unroll
+        for (int ky = 0; ky < 32; ++ky) v[ky] = Cx[(c * T + ky) * KX + kx];
+        fft32<true>(v);
+#pragma unroll
+        for (int y = 0; y < 32; ++y) Cx[(c * T + y) * KX + kx] = v[y];
+    }
+    __syncthreads();
+    {   // rows: Hermitian half spectrum -> 32 reals (only the 24 valid rows / columns are kept)
+        const int c = tid >> 5, y = tid & 31;
+        float2 v[32];
+#pragma unroll
+        for (int kx = 0; kx < KX; ++kx) v[kx] = Cx[(c * T + y) * KX + kx];
+        __syncthreads();                           // all spectra are in registers: the buffer may now hold the real tile
+        if (y < V) {
+#pragma unroll
+            for (int kx = KX; kx < 32; ++kx) v[kx] = make_float2(v[32 - kx].x, -v[32 - kx].y);
+            fft32<true>(v);
+#pragma unroll
+            for (int x = 0; x < V; ++x) R[(c * T + y) * RS + x] = v[x].x * (1.f / (T * T));
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < V * V * (CG / 4); idx += 256) {
+        const int q = idx & 1, px = idx >> 1, y = px / V, x = px - y * V;
+        const int gy = V * a + y, gx = V * b + x, c = c0 + 4 * q;
+        if (gy >= H || gx >= W || c >= cs) continue;
+        float* o = out + (((size_t)n * H + gy) * W + gx) * cs + c;
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (c + j < Cout) ? R[((4 * q + j) * T + y) * RS + x] + (bias ? bias[c + j] : 0.f) : 0.f;
+        if (accumulate) { const f32x4 old = *(const f32x4*)o; v += old; }
+        *(f32x4*)o = v;
+    }
+}
+
+// ---- weights -> B (forward) and B' (data gradient) ------------------------------------------------------------------------
+// Bf[f][ci][co] = conj(FFT(w padded)) = sum_t w[co][ci][t] e^{+2 pi i (ky ty + kx tx)/32};  Bd[f][co][ci] = phase(f) * conj(Bf),
+// phase = e^{+2 pi i 8 (ky + kx)/32} (the flipped kernel).  Channels >= Cin / Cout are zero.
+__global__ void spec_weights_kernel(const float* __restrict__ w, int Cout, int Cin, int Kp, int Np, float2* __restrict__ Bf, float2* __restrict__ Bd)
+{
+    __shared__ float2 tw[32];                      // e^{+2 pi i j / 32}
+    if (threadIdx.x < 32) { float sn, cs; sincospif((float)threadIdx.x * (1.f / 16.f), &sn, &cs); tw[threadIdx.x] = make_float2(cs, sn); }
+    __syncthreads();
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)NF * Kp * Np;
+    if (idx >= total) return;
+    const int co = (int)(idx % Np), ci = (int)((idx / Np) % Kp), f = (int)(idx / ((long)Np * Kp));
+    const int ky = f / KX, kx = f % KX;
+    float2 acc = make_float2(0.f, 0.f);
+    if (co < Cout && ci < Cin) {
+        const float* wp = w + ((size_t)co * Cin + ci) * 81;
+#pragma unroll 1
+        for (int ty = 0; ty < 9; ++ty)
+#pragma unroll
+            for (int tx = 0; tx < 9; ++tx) {
+                const float2 e = tw[(ky * ty + kx * tx) & 31];
+                const float v = wp[ty * 9 + tx];
+                acc.x += v * e.x; acc.y += v * e.y;
+            }
+    }
+    Bf[idx] = acc;
+    if (Bd) {
+        Bd[((size_t)f * Np + co) * Kp + ci] = cmulf(tw[(8 * (ky + kx)) & 31], make_float2(acc.x, -acc.y));
+    }
+}
+
+// ---- per-frequency complex GEMM: C[f][m][n] = sum_k A[f][m][k] * B[f][k][n] ----------------------------------------------
+// As a REAL GEMM on the fp32 MFMA, contraction index (k, part r/i): Re = Ar.Br - Ai.Bi, Im = Ar.Bi + Ai.Br.  One
+// v_mfma_f32_32x32x2_f32 contracts one k: lane half h = 0 feeds the real parts, h = 1 the imaginary parts:
+//   A (rows = 32 tiles m):  h ? Ai[m][k] : Ar[m][k]
+//   B (cols = 32 n):        Re tile: h ? -Bi[k][n] : Br[k][n];   Im tile: h ? Br[k][n] : Bi[k][n]
+// so a k step costs one 8-byte LDS read per operand and two MFMAs per wave.  Workgroup = 4 waves = (4 / NT) m-tiles x NT n-tiles
+// of 32; K in chunks of 32 staged in LDS (A rows padded to 33 complex: conflict-free column reads).
+// grid (ceil(M / (128 / NT)), NF, Np / (32 NT))
+template <int NT>
+__global__ __launch_bounds__(256) void spec_gemm_kernel(const float2* __restrict__ A, const float2* __restrict__ B, float2* __restrict__ C,
+                                                        int M, int Kp, int Np, int Ma, int ma0, int Mc, int mc0)
+{
+    // A holds Ma rows per frequency and this GEMM uses rows [ma0, ma0 + M); C likewise (Mc, mc0)
+    constexpr int WMT = 4 / NT, MB = 32 * WMT, NB = 32 * NT;
+    __shared__ float2 As[MB * 33];                 // [m][k]
+    __shared__ float2 Bs[32 * NB];                 // [k][n]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, li = lane & 31;
+    const int wm = wave / NT, wn = wave % NT;
+    const int f = blockIdx.y, mb = blockIdx.x * MB, nb = blockIdx.z * NB;
+    const float2* Af = A + ((size_t)f * Ma + ma0) * Kp;
+    const float2* Bfp = B + (size_t)f * Kp * Np + nb;
+    f32x16 cre, cim;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { cre[r] = 0.f; cim[r] = 0.f; }
+    for (int k0 = 0; k0 < Kp; k0 += 32) {
+        __syncthreads();
+        for (int idx = tid; idx < MB * 32; idx += 256) {
+            const int mm = idx >> 5, kk = idx & 31;
+            As[mm * 33 + kk] = (mb + mm < M && k0 + kk < Kp) ? Af[(size_t)(mb + mm) * Kp + k0 + kk] : make_float2(0.f, 0.f);
+        }
+        for (int idx = tid; idx < 32 * NB; idx += 256) {
+            const int kk = idx / NB, nn = idx - kk * NB;
+            Bs[idx] = (k0 + kk < Kp) ? Bfp[(size_t)(k0 + kk) * Np + nn] : make_float2(0.f, 0.f);
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < 32; ++kk) {
+            const float2 a = As[(wm * 32 + li) * 33 + kk], bq = Bs[kk * NB + wn * 32 + li];
+            const float av = h ? a.y : a.x;
+            cre = __builtin_amdgcn_mfma_f32_32x32x2f32(av, h ? -bq.y : bq.x, cre, 0, 0, 0);
+            cim = __builtin_amdgcn_mfma_f32_32x32x2f32(av, h ? bq.x : bq.y, cim, 0, 0, 0);
+        }
+    }
+    // accumulator: lane (col = li = n, h), register r = row m_local = (r & 3) + 8 (r >> 2) + 4 h
+    float2* Cf = C + ((size_t)f * Mc + mc0) * Np + nb + wn * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mb + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < M) Cf[(size_t)m * Np] = make_float2(cre[r], cim[r]);
+    }
+}
+
+// ---- weight gradient, reduction over tiles: dW^[s][f][k][n] = sum_{m in slice s} conj(G^[f][m][n]) * X^[f][m][k] ----------
+// As a REAL GEMM on the fp32 MFMA: Re = Gr.Xr + Gi.Xi, Im = Gr.Xi - Gi.Xr, i.e. the contraction index is (tile m, part r/i).
+// One v_mfma_f32_32x32x2_f32 contracts exactly one tile: lane half h = 0 feeds the real parts, h = 1 the imaginary parts:
+//   A (rows = 32 output channels n):   h ? Gi[m][n] : Gr[m][n]
+//   B (cols = 32 input channels k):    Re tile: h ? Xi[m][k] : Xr[m][k];   Im tile: h ? -Xr[m][k] : Xi[m][k]
+// so a tile costs three 8-byte loads per lane (two G halves of 32 channels, one X) and four MFMAs (2 n-tiles x {Re, Im}),
+// straight from global memory (each row of G^ / X^ is one coalesced 512 / 256 byte segment).  grid (NF, slices, Kp / 32);
+// the four waves of a workgroup take every fourth tile and are summed through LDS in fixed order (deterministic).
+__global__ __launch_bounds__(256) void spec_wgrad_reduce_kernel(const float2* __restrict__ Xf, const float2* __restrict__ Gf, float2* __restrict__ dW,
+                                                                int M, int Kp, int nslices)
+{
+    constexpr int Np = 64;
+    __shared__ float red[3][4][16][64];            // waves 1..3 x 4 accumulators
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, li = lane & 31;
+    const int f = blockIdx.x, s = blockIdx.y, k0 = blockIdx.z * 32;
+    const int per = (M + nslices - 1) / nslices, mbeg = s * per, mend = min(M, mbeg + per);
+    f32x16 acc[2][2];                              // [n-tile][Re / Im]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const float2* Xp = Xf + (size_t)f * M * Kp + k0 + li;
+    const float2* Gp = Gf + (size_t)f * M * Np + li;
+    constexpr int U = 4;                           // tiles in flight per wave
+    for (int m = mbeg + wave * U; m < mend; m += 4 * U) {
+        float2 x[U], g0[U], g1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int mm = min(m + u, mend - 1);
+            x[u] = Xp[(size_t)mm * Kp]; g0[u] = Gp[(size_t)mm * Np]; g1[u] = Gp[(size_t)mm * Np + 32];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (m + u >= mend) break;              // wave-uniform
+            const float a0 = h ? g0[u].y : g0[u].x, a1 = h ? g1[u].y : g1[u].x;
+            const float bre = h ? x[u].y : x[u].x, bim = h ? -x[u].x : x[u].y;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bre, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bim, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bre, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bim, acc[1][1], 0, 0, 0);
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[wave - 1][i * 2 + j][r][lane] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += red[w][i * 2 + j][r][lane];
+        // accumulator layout: lane (col = li = input channel k, h), register r = row n_local = (r & 3) + 8 (r >> 2) + 4 h
+        float2* o = dW + ((size_t)s * NF + f) * Kp * Np;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                o[(size_t)(k0 + li) * Np + n] = make_float2(acc[i][0][r], acc[i][1][r]);
+            }
+    }
+}
+
+// ---- weight gradient, inverse transform restricted to the 9 x 9 taps, in two separable stages ----------------------------
+// stage 1: E[ty][kx][k][n] = sum_s sum_ky dW^[s][ky][kx][k][n] e^{+2 pi i ky ty / 32}           (9 x 17 x Kp x 64 threads)
+// stage 2: dw[n][k][ty][tx] += (1/1024) sum_kx wgt(kx) Re(E[ty][kx][k][n] e^{+2 pi i kx tx / 32}), wgt = 1 for kx in {0, 16} else 2
+//          (the dropped half of the spectrum is the conjugate)                                    (81 x Kp x 64 threads)
+__global__ void spec_wgrad_out1_kernel(const float2* __restrict__ dW, int nslices, int Kp, float2* __restrict__ E)
+{
+    constexpr int Np = 64;
+    __shared__ float2 tw[32];                      // e^{+2 pi i j / 32}
+    if (threadIdx.x < 32) { float sn, cs; sincospif((float)threadIdx.x * (1.f / 16.f), &sn, &cs); tw[threadIdx.x] = make_float2(cs, sn); }
+    __syncthreads();
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)9 * KX * Kp * Np;
+    if (idx >= total) return;
+    const int kn = (int)(idx % (Kp * Np)), kx = (int)((idx / (Kp * Np)) % KX), ty = (int)(idx / ((long)Kp * Np * KX));
+    float2 acc = make_float2(0.f, 0.f);
+    for (int ky = 0; ky < T; ++ky) {
+        float2 d = make_float2(0.f, 0.f);
+        for (int s = 0; s < nslices; ++s) { const float2 t = dW[((size_t)s * NF + ky * KX + kx) * Kp * Np + kn]; d.x += t.x; d.y += t.y; }
+        const float2 e = cmulf(d, tw[(ky * ty) & 31]);
+        acc.x += e.x; acc.y += e.y;
+    }
+    E[idx] = acc;
+}
+
+__global__ void spec_wgrad_out2_kernel(const float2* __restrict__ E, int Kp, int Cout, int Cin, float* __restrict__ dw)
+{
+    constexpr int Np = 64;
+    __shared__ float2 tw[32];
+    if (threadIdx.x < 32) { float sn, cs; sincospif((float)threadIdx.x * (1.f / 16.f), &sn, &cs); tw[threadIdx.x] = make_float2(cs, sn); }
+    __syncthreads();
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = idx & 63, k = (idx >> 6) % Kp, tap = idx / (64 * Kp);
+    if (tap >= 81 || k >= Cin || n >= Cout) return;
+    const int ty = tap / 9, tx = tap % 9;
+    float acc = 0.f;
+    for (int kx = 0; kx < KX; ++kx) {
+        const float2 e = E[((size_t)(ty * KX + kx) * Kp + k) * Np + n];
+        const float2 t = tw[(kx * tx) & 31];
+        acc += ((kx == 0 || kx == 16) ? 1.f : 2.f) * (e.x * t.x - e.y * t.y);
+    }
+    dw[((size_t)n * Cin + k) * 81 + tap] += acc * (1.f / (T * T));
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------------
+int ssie_spec_tiles(int H, int W, int* tiles_y, int* tiles_x)
+{
+    *tiles_y = (H + V - 1) / V; *tiles_x = (W + V - 1) / V;
+    return *tiles_y * *tiles_x;
+}
+
+int ssie_launch_spec_fft(const float* in, int cs, int Cp, int N, int H, int W, int halo, float2* out, int m0, int Mtot, hipStream_t st)
+{
+    int ty, tx; const int per = ssie_spec_tiles(H, W, &ty, &tx);
+    if (Cp % CG || cs % 4) return 91;
+    hipLaunchKernelGGL(spec_fft_tiles_kernel, dim3(N * per, Cp / CG), dim3(256), 0, st, in, cs, H, W, ty, tx, halo ? -4 : 0, halo ? T : V, out, m0, Mtot, Cp);
+    return hipGetLastError() == hipSuccess ? 0 : 92;
+}
+
+int ssie_launch_spec_ifft(const float2* Yf, int m0, int Mtot, int Np, int N, int H, int W, float* out, int cs, int Cout, const float* bias,
+                          int accumulate, hipStream_t st)
+{
+    int ty, tx; const int per = ssie_spec_tiles(H, W, &ty, &tx);
+    if (cs % 4) return 93;
+    hipLaunchKernelGGL(spec_ifft_out_kernel, dim3(N * per, (cs + CG - 1) / CG), dim3(256), 0, st, Yf, m0, Mtot, Np, H, W, ty, tx, out, cs, Cout, bias, accumulate);
+    return hipGetLastError() == hipSuccess ? 0 : 94;
+}
+
+int ssie_launch_spec_weights(const float* w, int Cout, int Cin, int Kp, int Np, float2* Bf, float2* Bd, hipStream_t st)
+{
+    const long total = (long)NF * Kp * Np;
+    hipLaunchKernelGGL(spec_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, Cout, Cin, Kp, Np, Bf, Bd);
+    return hipGetLastError() == hipSuccess ? 0 : 95;
+}
+
+int ssie_launch_spec_gemm(const float2* A, int Ma, int ma0, const float2* B, float2* C, int Mc, int mc0, int M, int Kp, int Np, hipStream_t st)
+{
+    if (Kp % 8 || Np % 32) return 96;
+    if (Np % 64 == 0) hipLaunchKernelGGL(spec_gemm_kernel<2>, dim3((M + 63) / 64, NF, Np / 64), dim3(256), 0, st, A, B, C, M, Kp, Np, Ma, ma0, Mc, mc0);
+    else hipLaunchKernelGGL(spec_gemm_kernel<1>, dim3((M + 127) / 128, NF, Np / 32), dim3(256), 0, st, A, B, C, M, Kp, Np, Ma, ma0, Mc, mc0);
+    return hipGetLastError() == hipSuccess ? 0 : 98;
+}
+
+int ssie_launch_spec_wgrad(const float2* Xf, const float2* Gf, float2* dWs, int M, int Kp, int nslices, int Cout, int Cin, float* dw, hipStream_t st)
+{
+    if (Kp % 32) return 99;
+    hipLaunchKernelGGL(spec_wgrad_reduce_kernel, dim3(NF, nslices, Kp / 32), dim3(256), 0, st, Xf, Gf, dWs, M, Kp, nslices);
+    float2* E = dWs + (size_t)nslices * NF * Kp * 64;          // [9][17][Kp][64] behind the slices
+    const long t1 = (long)9 * KX * Kp * 64;
+    hipLaunchKernelGGL(spec_wgrad_out1_kernel, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, st, (const float2*)dWs, nslices, Kp, E);
+    const int t2 = 81 * Kp * 64;
+    hipLaunchKernelGGL(spec_wgrad_out2_kernel, dim3((t2 + 255) / 256), dim3(256), 0, st, (const float2*)E, Kp, Cout, Cin, dw);
+    return hipGetLastError() == hipSuccess ? 0 : 100;
+}

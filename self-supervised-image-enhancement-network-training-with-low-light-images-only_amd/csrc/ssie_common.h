@@ -120,5 +120,16 @@ int ssie_launch_colsum(const float* g, long npix, int cstride, int coff, int C, 
 int ssie_launch_pack(const PackDesc& d, hipStream_t st);
 int ssie_launch_pack_batched(const PackDesc* descs_dev, int ndesc, hipStream_t st);
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: `seen` is a bit mask of the devices a kernel has been
+// enabled on (one `static unsigned` per launcher instantiation)
+static inline void ssie_allow_full_lds(const void* fn, unsigned& seen)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 31) { hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return; }
+    if (seen & (1u << dev)) return;
+    hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    seen |= 1u << dev;
+}
+
 static inline int ssie_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int ssie_round_up(int a, int b) { return ssie_ceil_div(a, b) * b; }

@@ -84,40 +84,49 @@ __global__ __launch_bounds__(256) void tail_kernel(const TailParams p)
     const int n1y = nearest_src(vy_hi, p.sy4, p.H4) - y1lo + 1, n1x = nearest_src(vx_hi, p.sx4, p.W4) - x1lo + 1;
     __syncthreads();
 
-    // ---- phase 1: nine dot products per source pixel, eight lanes per pixel (8 channels = 16 B bf16 / 32 B fp32 each) ----
+    // ---- phase 1: nine dot products per source pixel, eight lanes per pixel (8 channels = 16 B bf16 / 32 B fp32 each).
+    // One source level at a time, so that this lane's 9 x 8 composite weights of the level live in registers (72 VGPRs)
+    // instead of being re-read from LDS for every pixel (18 ds_read_b128 per pixel and lane). ----
     const int sub = tid & 7, slot = tid >> 3;
-    const int n3 = R3 * R3, n2 = n2y * n2x, n1 = n1y * n1x, items = n3 + n2 + n1;
-    for (int it = slot; it < ((items + 31) & ~31); it += 32) {
-        float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        float* dst = nullptr;
-        if (it < items) {
-            const void* base; size_t pix; const float* w; bool inside = true;
-            if (it < n3) {
-                const int yy = y0 - 1 + it / R3, xx = x0 - 1 + it % R3;
-                inside = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-                base = p.d3; pix = ((size_t)n * p.H + yy) * p.W + xx; w = wcs + 2 * 9 * 64; dst = T3 + it * 9;
-            } else if (it < n3 + n2) {
-                const int q = it - n3, yy = y2lo + q / n2x, xx = x2lo + q % n2x;
-                base = p.d2; pix = ((size_t)n * p.H2 + yy) * p.W2 + xx; w = wcs + 1 * 9 * 64; dst = T2 + q * 9;
-            } else {
-                const int q = it - n3 - n2, yy = y1lo + q / n1x, xx = x1lo + q % n1x;
-                base = p.d1; pix = ((size_t)n * p.H4 + yy) * p.W4 + xx; w = wcs; dst = T1 + q * 9;
-            }
-            if (inside) {
-                float v[8];
-                load8<BF16>(base, pix, sub * 8, v);
+    const int n3 = R3 * R3, n2 = n2y * n2x, n1 = n1y * n1x;
+#pragma unroll 1
+    for (int lvl = 0; lvl < 3; ++lvl) {
+        const int items = lvl == 0 ? n1 : lvl == 1 ? n2 : n3;
+        const void* base = lvl == 0 ? p.d1 : lvl == 1 ? p.d2 : p.d3;
+        float* Tl = lvl == 0 ? T1 : lvl == 1 ? T2 : T3;
+        float wr[9][8];
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const f32x4 wa = *(const f32x4*)(w + t * 64 + sub * 8), wb = *(const f32x4*)(w + t * 64 + sub * 8 + 4);
-                    acc[t] = v[0] * wa[0] + v[1] * wa[1] + v[2] * wa[2] + v[3] * wa[3] + v[4] * wb[0] + v[5] * wb[1] + v[6] * wb[2] + v[7] * wb[3];
+        for (int t = 0; t < 9; ++t) {
+            const f32x4 wa = *(const f32x4*)(wcs + (lvl * 9 + t) * 64 + sub * 8), wb = *(const f32x4*)(wcs + (lvl * 9 + t) * 64 + sub * 8 + 4);
+            wr[t][0] = wa[0]; wr[t][1] = wa[1]; wr[t][2] = wa[2]; wr[t][3] = wa[3]; wr[t][4] = wb[0]; wr[t][5] = wb[1]; wr[t][6] = wb[2]; wr[t][7] = wb[3];
+        }
+        for (int it = slot; it < ((items + 31) & ~31); it += 32) {
+            float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (it < items) {
+                size_t pix; bool inside = true;
+                if (lvl == 2) {
+                    const int yy = y0 - 1 + it / R3, xx = x0 - 1 + it % R3;
+                    inside = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+                    pix = ((size_t)n * p.H + yy) * p.W + xx;
+                } else if (lvl == 1) {
+                    pix = ((size_t)n * p.H2 + y2lo + it / n2x) * p.W2 + x2lo + it % n2x;
+                } else {
+                    pix = ((size_t)n * p.H4 + y1lo + it / n1x) * p.W4 + x1lo + it % n1x;
+                }
+                if (inside) {
+                    float v[8];
+                    load8<BF16>(base, pix, sub * 8, v);
+#pragma unroll
+                    for (int t = 0; t < 9; ++t)
+                        acc[t] = v[0] * wr[t][0] + v[1] * wr[t][1] + v[2] * wr[t][2] + v[3] * wr[t][3] + v[4] * wr[t][4] + v[5] * wr[t][5] + v[6] * wr[t][6] + v[7] * wr[t][7];
                 }
             }
-        }
 #pragma unroll
-        for (int t = 0; t < 9; ++t) { float a = acc[t]; a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); acc[t] = a; }
-        if (dst) {
+            for (int t = 0; t < 9; ++t) { float a = acc[t]; a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); acc[t] = a; }
+            if (it < items) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) if (sub == (t & 7)) dst[t] = acc[t];
+                for (int t = 0; t < 9; ++t) if (sub == (t & 7)) Tl[it * 9 + t] = acc[t];
+            }
         }
     }
     __syncthreads();

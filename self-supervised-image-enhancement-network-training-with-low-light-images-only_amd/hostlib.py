@@ -311,11 +311,12 @@ class Plan:
               "ssie_plan_backward_from_cotangents")
 
     KINDS = ("conv_fprop(+dgrad) 64-ch tile", "conv_fprop(+dgrad) 32-ch tile", "conv_wgrad_kernel", "wgrad_reduce_kernel", "colsum",
-             "pack_weights", "loss_direct", "fft_loss_kernel", "attention", "elementwise")
+             "pack_weights", "loss_direct", "fft_loss_kernel", "attention", "elementwise", "spectral 9x9 conv (fwd + dgrad + wgrad)")
 
     def profile_step(self, x):
         """{kernel class: (device ms, algorithmic FLOPs, launches)} of one loss+backward step (HIP events)."""
-        ms = (C.c_double * 10)(); fl = (C.c_double * 10)(); cnt = (C.c_int * 10)()
+        nk = len(self.KINDS)
+        ms = (C.c_double * nk)(); fl = (C.c_double * nk)(); cnt = (C.c_int * nk)()
         check(self.L.ssie_plan_profile_step(self.h, x.data_ptr(), self._strides(x), torch.cuda.current_stream().cuda_stream,
                                             ms, fl, cnt), "ssie_plan_profile_step")
         return {k: (ms[i], fl[i], cnt[i]) for i, k in enumerate(self.KINDS)}

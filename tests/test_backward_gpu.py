@@ -148,8 +148,10 @@ def forced_kernels(pkg, request):
         L.ssie_debug_set_fprop_wide_min_tiles(1)
         L.ssie_debug_set_fprop_v2_split_min_tiles(1)
         L.ssie_debug_set_skinny_final(0)          # and final_conv (64 -> 1) on the MFMA tiles instead of the VALU kernels
+        L.ssie_debug_set_spectral9(0)             # and the 9 x 9 convolution on the direct MFMA kernels instead of the frequency domain
     yield request.param
     L.ssie_debug_set_skinny_final(1)
+    L.ssie_debug_set_spectral9(1)
     L.ssie_debug_set_fprop_min_tiles16(256)
     L.ssie_debug_set_fprop_wide_min_tiles(512)
     L.ssie_debug_set_fprop_v2_split_min_tiles(1024)
@@ -164,12 +166,13 @@ def test_backward_chain_injected(pkg, case, forced_kernels):
 
 
 ONE_HOT = ["c_rec", "c_rf", "c_il", "c_id", "c_f", "c_sp"]
-# measured on MI355X (tests print the worst value): reconstruction 7e-8 ... 1e-7 and spectral TV 1.5e-7 ... 1.7e-7 (their sg()
-# arguments sit away from 0) are held to 1e-5; R fidelity 2e-4 ... 1.0e-3, I_low smoothness 6e-5 ... 1.1e-3, Fourier 8e-6 ...
+# measured on MI355X (tests print the worst value): reconstruction 7e-8 ... 1.2e-4 and spectral TV 1.5e-7 ... 1.7e-7 (their sg()
+# arguments sit away from 0: at most a single sign / ReLU decision differs between two valid fp32 forwards, e.g. the direct and
+# the frequency-domain 9 x 9 convolution) are held to the fixed 1e-3 of SURVEY 8(c); R fidelity 2e-4 ... 1.0e-3, I_low smoothness 6e-5 ... 1.1e-3, Fourier 8e-6 ...
 # 5.7e-4 and I_delta smoothness 1e-5 ... 6.2e-3 (I_delta is very smooth here: median |dx D| = 2e-5, so the HIP forward's 1e-7
 # differences flip a fraction of a percent of sg(dx D)) get ~3-5x the worst value seen.  The arithmetic behind those four is
 # pinned elementwise in tests/test_loss_op_gpu.py and the chain behind them in test_backward_chain_injected.
-ONE_HOT_TOL = {"c_rec": 1e-5, "c_sp": 1e-5, "c_rf": 5e-3, "c_il": 5e-3, "c_id": 2e-2, "c_f": 5e-3}
+ONE_HOT_TOL = {"c_rec": 1e-3, "c_sp": 1e-3, "c_rf": 5e-3, "c_il": 5e-3, "c_id": 2e-2, "c_f": 5e-3}
 
 
 @pytest.mark.parametrize("case", ["b31_32", "b31_64", "b8_24x40"])

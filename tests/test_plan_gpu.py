@@ -29,7 +29,8 @@ CASES = {
     "b5_256": (1, 5, 256, 256, O.JYU_COEFS),         # patch_size 256 (model.py:456-473 takes any): three-pass Fourier loss
     "b4_160x288": (1, 4, 160, 288, O.JYU_COEFS),     # above the LDS plane limit and not powers of two: three-pass direct DFT
 }
-GRAD_FLOOR = {"b256_64": 5e-3}     # 256 bands: cotangent noise 5-7e-2, deep-layer gradients see ~3e-3 of it
+GRAD_FLOOR = {"b256_64": 1e-2}     # 256 bands: cotangent noise 5-7e-2, deep-layer gradients see 3-7e-3 of it (which signs flip moves with
+                                   # every 1e-7 change of the forward; the noise-free pin of this case is tests/test_backward_gpu.py at 2e-5)
 
 
 @pytest.fixture(scope="module")
@@ -66,8 +67,10 @@ def forced_kernels(pkg, request):
         L.ssie_debug_set_fprop_wide_min_tiles(1)
         L.ssie_debug_set_fprop_v2_split_min_tiles(1)
         L.ssie_debug_set_skinny_final(0)          # and final_conv (64 -> 1) on the MFMA tiles instead of the VALU kernels
+        L.ssie_debug_set_spectral9(0)             # and the 9 x 9 convolution on the direct MFMA kernels instead of the frequency domain
     yield request.param
     L.ssie_debug_set_skinny_final(1)
+    L.ssie_debug_set_spectral9(1)
     L.ssie_debug_set_fprop_min_tiles16(256)
     L.ssie_debug_set_fprop_wide_min_tiles(512)
     L.ssie_debug_set_fprop_v2_split_min_tiles(1024)
