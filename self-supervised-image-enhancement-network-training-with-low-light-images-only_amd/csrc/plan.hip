@@ -50,7 +50,7 @@ struct Plan {
     size_t slab_off = 0, slab_off2 = 0, slab_cap = 0, partial_off = 0, packdesc_off = 0, mask_off = 0, scal_off = 0;
     size_t lpart_off = 0, fpart_off = 0, counter_off = 0, fftws_off = 0, tailw_off = 0, skinny_off = 0;
     // frequency-domain 9 x 9 convolution (spectral_conv.hip): tiles per pass, padded band count, buffers (float offsets)
-    bool spectral = false; int sp_Mt = 0, sp_Kp = 0, sp_slices = 8;
+    bool spectral = false; int sp_Mt = 0, sp_Kp = 0, sp_slices = 2;      // 544 frequencies x 2 slices = 1 088 reduction workgroups
     size_t sp_Xf = 0, sp_Yf = 0, sp_Zf = 0, sp_Gn = 0, sp_Bf = 0, sp_Bd = 0, sp_dW = 0;
     int counter_cursor = 0;
     int loss_blocks = 0, fft_blocks = 0;

@@ -70,7 +70,7 @@ constexpr int CG = 8;                              // channels per workgroup of 
 constexpr int RS = T + 1;                          // padded row stride of the real tile in LDS
 
 // ---- x -> X^ ------------------------------------------------------------------------------------------------------------
-// grid (tiles of this tensor, Cp / 8); window origin = (V*a + org, V*b + org); `valid` = 32 for halo windows (org = -4),
+// grid (Cp / 8, tiles of this tensor); window origin = (V*a + org, V*b + org); `valid` = 32 for halo windows (org = -4),
 // 24 for the zero-padded gradient tiles of the weight gradient (org = 0)
 __global__ __launch_bounds__(256) void spec_fft_tiles_kernel(const float* __restrict__ in, int cs, int H, int W, int tiles_y, int tiles_x,
                                                              int org, int valid, float2* __restrict__ out, int m0, int Mtot, int Cp)
@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void spec_fft_tiles_kernel(const float* __rest
     float* R = (float*)buf;                        // [CG][T][RS] floats  (33.8 KB of the 34.8 KB)
     float2* Cx = buf;                              // [CG][T][KX] complex
     static_assert(CG * T * RS * 4 <= CG * T * KX * 8, "R must fit inside Cx");
-    const int tid = threadIdx.x, mloc = blockIdx.x, c0 = blockIdx.y * CG;
+    // channel group = blockIdx.x (fastest): the groups of one tile run side by side and share the tile's cache lines
+    const int tid = threadIdx.x, mloc = blockIdx.y, c0 = blockIdx.x * CG;
     const int b = mloc % tiles_x, a = (mloc / tiles_x) % tiles_y, n = mloc / (tiles_x * tiles_y);
     const int oy = V * a + org, ox = V * b + org;
     for (int idx = tid; idx < T * T * (CG / 4); idx += 256) {
@@ -123,14 +124,14 @@ __global__ __launch_bounds__(256) void spec_fft_tiles_kernel(const float* __rest
 }
 
 // ---- Y^ -> y ------------------------------------------------------------------------------------------------------------
-// grid (tiles, ceil(Cout_pad / 8)); writes the 24 x 24 valid block of tile m: out = (accumulate ? out : 0) + y + bias
+// grid (ceil(cs / 8), tiles); writes the 24 x 24 valid block of tile m: out = (accumulate ? out : 0) + y + bias
 __global__ __launch_bounds__(256) void spec_ifft_out_kernel(const float2* __restrict__ Yf, int m0, int Mtot, int Np, int H, int W, int tiles_y, int tiles_x,
                                                             float* __restrict__ out, int cs, int Cout, const float* __restrict__ bias, int accumulate)
 {
     __shared__ float2 buf[CG * T * KX];            // Cx, then (after a barrier) the real tile R: see spec_fft_tiles_kernel
     float* R = (float*)buf;
     float2* Cx = buf;
-    const int tid = threadIdx.x, mloc = blockIdx.x, c0 = blockIdx.y * CG;
+    const int tid = threadIdx.x, mloc = blockIdx.y, c0 = blockIdx.x * CG;
     const int b = mloc % tiles_x, a = (mloc / tiles_x) % tiles_y, n = mloc / (tiles_x * tiles_y);
     const size_t m = (size_t)m0 + mloc;
     for (int idx = tid; idx < NF * CG; idx += 256) {
@@ -284,25 +285,37 @@ __global__ __launch_bounds__(256) void spec_wgrad_reduce_kernel(const float2* __
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const float2* Xp = Xf + (size_t)f * M * Kp + k0 + li;
     const float2* Gp = Gf + (size_t)f * M * Np + li;
-    constexpr int U = 4;                           // tiles in flight per wave
-    for (int m = mbeg + wave * U; m < mend; m += 4 * U) {
-        float2 x[U], g0[U], g1[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int mm = min(m + u, mend - 1);
-            x[u] = Xp[(size_t)mm * Kp]; g0[u] = Gp[(size_t)mm * Np]; g1[u] = Gp[(size_t)mm * Np + 32];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (m + u >= mend) break;              // wave-uniform
-            const float a0 = h ? g0[u].y : g0[u].x, a1 = h ? g1[u].y : g1[u].x;
-            const float bre = h ? x[u].y : x[u].x, bim = h ? -x[u].x : x[u].y;
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bre, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bim, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bre, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bim, acc[1][1], 0, 0, 0);
+    constexpr int U = 4;                           // tiles per batch; the NEXT batch's 12 loads are in flight under this batch's 16 MFMAs
+    float2 x[2][U], g0[2][U], g1[2][U];
+#define WG_LOAD(BUF, M0)                                                                                  \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                       \
+        const int mm_ = min((M0) + u, mend - 1);                                                          \
+        x[BUF][u] = Xp[(size_t)mm_ * Kp]; g0[BUF][u] = Gp[(size_t)mm_ * Np]; g1[BUF][u] = Gp[(size_t)mm_ * Np + 32]; \
+    }
+#define WG_MFMA(BUF, M0)                                                                                  \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                       \
+        if ((M0) + u < mend) {                                                                            \
+            const float a0 = h ? g0[BUF][u].y : g0[BUF][u].x, a1 = h ? g1[BUF][u].y : g1[BUF][u].x;       \
+            const float bre = h ? x[BUF][u].y : x[BUF][u].x, bim = h ? -x[BUF][u].x : x[BUF][u].y;        \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bre, acc[0][0], 0, 0, 0);                \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bim, acc[0][1], 0, 0, 0);                \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bre, acc[1][0], 0, 0, 0);                \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bim, acc[1][1], 0, 0, 0);                \
+        }                                                                                                 \
+    }
+    int m = mbeg + wave * U;
+    if (m < mend) WG_LOAD(0, m)
+    for (; m < mend; m += 8 * U) {                 // two batches per trip so that the buffer index is a compile-time constant
+        const int m1 = m + 4 * U;
+        if (m1 < mend) WG_LOAD(1, m1)
+        WG_MFMA(0, m)
+        if (m1 < mend) {
+            if (m1 + 4 * U < mend) WG_LOAD(0, m1 + 4 * U)
+            WG_MFMA(1, m1)
         }
     }
+#undef WG_LOAD
+#undef WG_MFMA
     if (wave > 0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -389,7 +402,7 @@ int ssie_launch_spec_fft(const float* in, int cs, int Cp, int N, int H, int W, i
 {
     int ty, tx; const int per = ssie_spec_tiles(H, W, &ty, &tx);
     if (Cp % CG || cs % 4) return 91;
-    hipLaunchKernelGGL(spec_fft_tiles_kernel, dim3(N * per, Cp / CG), dim3(256), 0, st, in, cs, H, W, ty, tx, halo ? -4 : 0, halo ? T : V, out, m0, Mtot, Cp);
+    hipLaunchKernelGGL(spec_fft_tiles_kernel, dim3(Cp / CG, N * per), dim3(256), 0, st, in, cs, H, W, ty, tx, halo ? -4 : 0, halo ? T : V, out, m0, Mtot, Cp);
     return hipGetLastError() == hipSuccess ? 0 : 92;
 }
 
@@ -398,7 +411,7 @@ int ssie_launch_spec_ifft(const float2* Yf, int m0, int Mtot, int Np, int N, int
 {
     int ty, tx; const int per = ssie_spec_tiles(H, W, &ty, &tx);
     if (cs % 4) return 93;
-    hipLaunchKernelGGL(spec_ifft_out_kernel, dim3(N * per, (cs + CG - 1) / CG), dim3(256), 0, st, Yf, m0, Mtot, Np, H, W, ty, tx, out, cs, Cout, bias, accumulate);
+    hipLaunchKernelGGL(spec_ifft_out_kernel, dim3((cs + CG - 1) / CG, N * per), dim3(256), 0, st, Yf, m0, Mtot, Np, H, W, ty, tx, out, cs, Cout, bias, accumulate);
     return hipGetLastError() == hipSuccess ? 0 : 94;
 }
 

@@ -169,10 +169,10 @@ ONE_HOT = ["c_rec", "c_rf", "c_il", "c_id", "c_f", "c_sp"]
 # measured on MI355X (tests print the worst value): reconstruction 7e-8 ... 1.2e-4 and spectral TV 1.5e-7 ... 1.7e-7 (their sg()
 # arguments sit away from 0: at most a single sign / ReLU decision differs between two valid fp32 forwards, e.g. the direct and
 # the frequency-domain 9 x 9 convolution) are held to the fixed 1e-3 of SURVEY 8(c); R fidelity 2e-4 ... 1.0e-3, I_low smoothness 6e-5 ... 1.1e-3, Fourier 8e-6 ...
-# 5.7e-4 and I_delta smoothness 1e-5 ... 6.2e-3 (I_delta is very smooth here: median |dx D| = 2e-5, so the HIP forward's 1e-7
+# 8.8e-3 (32 x 32 planes: one flipped sg(|F(S)| - |F(x)|) bin is 1/1024 of a plane) and I_delta smoothness 1e-5 ... 6.2e-3 (I_delta is very smooth here: median |dx D| = 2e-5, so the HIP forward's 1e-7
 # differences flip a fraction of a percent of sg(dx D)) get ~3-5x the worst value seen.  The arithmetic behind those four is
 # pinned elementwise in tests/test_loss_op_gpu.py and the chain behind them in test_backward_chain_injected.
-ONE_HOT_TOL = {"c_rec": 1e-3, "c_sp": 1e-3, "c_rf": 5e-3, "c_il": 5e-3, "c_id": 2e-2, "c_f": 5e-3}
+ONE_HOT_TOL = {"c_rec": 1e-3, "c_sp": 1e-3, "c_rf": 5e-3, "c_il": 5e-3, "c_id": 2e-2, "c_f": 2e-2}
 
 
 @pytest.mark.parametrize("case", ["b31_32", "b31_64", "b8_24x40"])
