@@ -63,13 +63,15 @@ def host_threads():
     return max(1, min(ncpu, int(os.environ.get("SSIE_CPU_THREADS", "16"))))
 
 
-def dominant_traffic(kernel_substr):
+def dominant_traffic(kernel_substr, workload):
     """HBM bytes per launch of ONE kernel (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc passes over this same
-    command, MI355X_MICROARCH.md HBM section) from the newest committed profile of THIS round; PMC counters cannot be read
-    from inside the process.  -> (bytes or None, kernel name, source file)"""
+    command, MI355X_MICROARCH.md HBM section) from the committed profile of THIS round and THIS workload (final pass first,
+    then the mid-round one); PMC counters cannot be read from inside the process.  -> (bytes or None, kernel name, source file)"""
     try:
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_*_hbm_traffic.json")))
-        for f in reversed(files):
+        for tag in ("r02_final", "r02_mid"):
+            f = os.path.join(ROOT, "profiles", f"{tag}_{workload}_hbm_traffic.json")
+            if not os.path.exists(f):
+                continue
             tj = json.load(open(f))["kernels"]
             cand = {k: v for k, v in tj.items() if kernel_substr in k}
             if cand:
@@ -147,7 +149,7 @@ def run_train(args, torch, dist, hostlib, model, world, rank, dev):
         ms, fl, cnt = agg[dom]
         ach = fl / (ms * 1e-3) / 1e12
         sub = "conv_wgrad_kernel" if "wgrad" in dom else "conv_fprop_v2w_kernel" if bands <= 64 else "conv_fprop_v2"
-        traffic, tk, tsrc = dominant_traffic(sub)
+        traffic, tk, tsrc = dominant_traffic(sub, args.workload)
         out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": traffic, "traffic_kernel": tk, "traffic_source": tsrc,
                            "launches_per_step": cnt // reps, "avg_launch_ms": round(ms / cnt, 4),
@@ -266,7 +268,7 @@ def run_infer(args, torch, hostlib, model, dev):
         alg_bytes = infer_algorithmic_bytes(hw, bands, bf16)
         t_mfma = gflop / 1e3 / peak * 1e3                       # ms
         t_hbm = alg_bytes / (PEAK_HBM_TBS * 1e12) * 1e3
-        traffic, tk, tsrc = dominant_traffic("conv_fprop_bf16" if bf16 else "conv_fprop_v2")
+        traffic, tk, tsrc = dominant_traffic("conv_fprop_bf16" if bf16 else "conv_fprop_v2", args.workload)
         out["roofline"] = {"kernel": dom, "bound": "mfma" if t_mfma >= t_hbm else "hbm", "achieved": round(ach, 2), "peak": peak,
                            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_kernel": tk, "traffic_source": tsrc,
                            "launches_per_step": dcnt // reps, "avg_launch_ms": round(dms / dcnt, 4),
