@@ -709,15 +709,62 @@ __device__ __forceinline__ void ssie_pack_one(const PackDesc& d, long idx4)
     ((f32x4*)d.dst)[idx4] = v;
 }
 
+// Winograd F(2x2, 3x3) weights: one thread = one (chunk, q, n) column of 4 input channels -> the 16 transform positions
+// U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; g[r][s] = the tap with (dy, dx) = (r-1, s-1) (PackDesc.tapsel[r*3+s])
+__device__ __forceinline__ void ssie_pack_wino_one(const PackDesc& d, long idx)
+{
+    const long total = (long)d.nchunks * 4 * d.Npad;
+    if (idx >= total) return;
+    const int n = (int)(idx % d.Npad); long r = idx / d.Npad;
+    const int q = (int)(r & 3); const int chunk = (int)(r >> 2);
+    const int kb = chunk * 16 + (q >> 1) * 8 + (q & 1) * 4;
+    f32x4 g[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int ts = (int)d.tapsel[t] * d.s_t;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = kb + s;
+            g[t][s] = (k < d.K && n < d.N) ? d.w[(long)n * d.s_n + (long)k * d.s_k + ts] : 0.f;
+        }
+    }
+    f32x4 m[12];      // G g: 4 x 3
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        m[0 * 3 + s] = g[0 * 3 + s];
+        m[1 * 3 + s] = 0.5f * (g[0 * 3 + s] + g[1 * 3 + s] + g[2 * 3 + s]);
+        m[2 * 3 + s] = 0.5f * (g[0 * 3 + s] - g[1 * 3 + s] + g[2 * 3 + s]);
+        m[3 * 3 + s] = g[2 * 3 + s];
+    }
+    f32x4* dst = (f32x4*)d.dst;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f32x4 u[4];
+        u[0] = m[i * 3 + 0];
+        u[1] = 0.5f * (m[i * 3 + 0] + m[i * 3 + 1] + m[i * 3 + 2]);
+        u[2] = 0.5f * (m[i * 3 + 0] - m[i * 3 + 1] + m[i * 3 + 2]);
+        u[3] = m[i * 3 + 2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[((size_t)(chunk * 16 + i * 4 + j) * 4 + q) * d.Npad + n] = u[j];
+    }
+}
+
 __global__ void pack_weights_kernel(const PackDesc d)
 {
-    ssie_pack_one(d, (long)blockIdx.x * blockDim.x + threadIdx.x);
+    if (d.wino) ssie_pack_wino_one(d, (long)blockIdx.x * blockDim.x + threadIdx.x);
+    else ssie_pack_one(d, (long)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // batched: descriptors resident in device memory, blockIdx.y selects the descriptor
 __global__ void pack_weights_batched_kernel(const PackDesc* __restrict__ descs)
 {
     const PackDesc& d = descs[blockIdx.y];
+    if (d.wino) {
+        const long total = (long)d.nchunks * 4 * d.Npad;
+        for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x)
+            ssie_pack_wino_one(d, idx);
+        return;
+    }
     long total4 = (long)d.nchunks * d.T * 4 * d.Npad;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += (long)gridDim.x * blockDim.x)
         ssie_pack_one(d, idx);
@@ -764,6 +811,7 @@ static int ssie_launch_fprop_nt1(const ConvParams& p, hipStream_t st)
 
 int ssie_launch_fprop(const ConvParams& p, hipStream_t st)
 {
+    if (p.wino) return ssie_launch_fprop_wino(p, st);
     if (ssie_fprop_use_v2 && ssie_fprop_v2_ok(p)) return ssie_launch_fprop_v2(p, st);
     int nt = (p.Cout_pad % 64 == 0) ? 2 : 1;
     if (nt == 2 && (long)p.N * p.tiles_y * p.tiles_x * p.co_blocks < 256) {

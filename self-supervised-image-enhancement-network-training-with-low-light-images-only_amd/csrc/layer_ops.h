@@ -15,6 +15,10 @@ TapList ssie_taps_transposed(int k, int pad, int py, int px);
 SrcDesc ssie_make_src(const float* ptr, int C, int cstride, int coff, int Hs, int Ws, int Hv, int Wv);
 size_t ssie_packed_floats(int K, int N, int T);
 PackDesc ssie_make_pack(const float* w, float* dst, int K, int N, const TapList& t, int s_k, int s_n, int s_t);
+size_t ssie_wino_packed_floats(int K, int N);
+bool ssie_wino_eligible(const ConvParams& p, const TapList& t);
+PackDesc ssie_make_pack_wino(const float* w, float* dst, int K, int N, const TapList& t, int s_k, int s_n, int s_t);
+void ssie_conv_to_wino(ConvParams& p, const float* u);
 PackDesc ssie_make_pack_bf16(const float* w, float* dst, int K, int N, const TapList& t, int s_k, int s_n, int s_t);
 int ssie_make_conv(ConvParams& p, const SrcDesc* srcs, int nsrc, int N, int Hv, int Wv, const TapList& t, int si,
                    int Ho, int Wo, const float* wpacked, int Cout,

@@ -159,6 +159,56 @@ int ssie_make_conv_bf16(ConvParams& p, const SrcDesc* srcs, int nsrc, int N, int
     return 0;
 }
 
+// ---- Winograd F(2x2, 3x3) (conv_wino.hip) ----
+int ssie_fprop_wino = 1;              // A/B switch: 1 = eligible stride-1 3x3 launches run conv_wino_kernel
+int ssie_fprop_wino_min_tiles = 256;  // ... when the launch has at least this many 16 x 32 x 32-channel tiles (tests set 1)
+extern "C" void ssie_debug_set_wino(int v) { ssie_fprop_wino = v; }
+extern "C" void ssie_debug_set_wino_min_tiles(int v) { ssie_fprop_wino_min_tiles = v; }
+
+size_t ssie_wino_packed_floats(int K, int N)
+{
+    const int npad = N > 32 ? ssie_round_up(N, 64) : 32;
+    return (size_t)ssie_ceil_div(K, SSIE_CK) * 16 * 16 * npad;
+}
+
+// a full 3 x 3 tap list with offsets in [-1, 1]^2 (forward or flipped data-gradient order)
+static bool taps_are_3x3(const TapList& t)
+{
+    if (t.n != 9) return false;
+    int seen = 0;
+    for (int i = 0; i < 9; ++i) {
+        if (t.dy[i] < -1 || t.dy[i] > 1 || t.dx[i] < -1 || t.dx[i] > 1) return false;
+        seen |= 1 << ((t.dy[i] + 1) * 3 + t.dx[i] + 1);
+    }
+    return seen == 0x1ff;
+}
+
+// would conv_wino_kernel take this launch?  (geometry from ssie_make_conv, its tap list)
+bool ssie_wino_eligible(const ConvParams& p, const TapList& t)
+{
+    if (!ssie_fprop_wino || !taps_are_3x3(t) || p.si != 1 || p.so != 1 || p.py || p.px) return false;
+    if (p.Ho != p.Hv || p.Wo != p.Wv || p.Hout != p.Ho || p.Wout != p.Wo) return false;
+    const long tiles = (long)p.N * ssie_ceil_div(p.Ho, 16) * ssie_ceil_div(p.Wo, 32) * (p.Cout_pad / 32);
+    return tiles >= ssie_fprop_wino_min_tiles;
+}
+
+PackDesc ssie_make_pack_wino(const float* w, float* dst, int K, int N, const TapList& t, int s_k, int s_n, int s_t)
+{
+    PackDesc d = ssie_make_pack(w, dst, K, N, t, s_k, s_n, s_t);
+    d.wino = 1;
+    for (int i = 0; i < 9; ++i) d.tapsel[(t.dy[i] + 1) * 3 + t.dx[i] + 1] = t.sel[i];
+    return d;
+}
+
+// re-target a stride-1 3 x 3 geometry at conv_wino_kernel: 16 x 32 tiles, 32-channel blocks, weights = U
+void ssie_conv_to_wino(ConvParams& p, const float* u)
+{
+    p.wino = 1; p.wpacked = u;
+    p.th = 16; p.tw = 32; p.hp_h = 18; p.hp_w = 34;
+    p.tiles_y = ssie_ceil_div(p.Ho, 16); p.tiles_x = ssie_ceil_div(p.Wo, 32);
+    p.co_blocks = p.Cout_pad / 32;
+}
+
 PackDesc ssie_make_pack_bf16(const float* w, float* dst, int K, int N, const TapList& t, int s_k, int s_n, int s_t)
 {
     PackDesc d = ssie_make_pack(w, dst, K, N, t, s_k, s_n, s_t);
@@ -255,16 +305,20 @@ extern "C" int ssie_conv2d_fwd(const ssie_src_t* srcs, int nsrc, int N, int Hv, 
     const int Ho = (Hv + 2 * pad - k) / stride + 1, Wo = (Wv + 2 * pad - k) / stride + 1;
     char* cur = (char*)ws; char* end = cur + ws_bytes;
     if (cin_w > cin || ssie_ceil_div(cin_w, SSIE_CK) != ssie_ceil_div(cin, SSIE_CK)) return SSIE_E_SHAPE;
-    float* wp = ws_take(cur, end, ssie_packed_floats(cin_w, cout, T));
+    const size_t wf = ssie_packed_floats(cin_w, cout, T), uf = k == 3 ? ssie_wino_packed_floats(cin_w, cout) : 0;
+    float* wp = ws_take(cur, end, wf > uf ? wf : uf);
     if (!wp) return SSIE_E_WORKSPACE;
     TapList t = ssie_taps_conv(k);
-    PackDesc pd = ssie_make_pack(weight, wp, cin_w, cout, t, /*s_k*/ T, /*s_n*/ cin_w * T, 1);
     hipStream_t st = (hipStream_t)stream;
-    if (ssie_launch_pack(pd, st)) return SSIE_E_LAUNCH;
     Epilogue e; memset(&e, 0, sizeof(e)); e.bias = bias; e.act = act; e.addsrc = addsrc; e.out2 = out2;
     ConvParams p;
     int rc = ssie_make_conv(p, sd, nsrc, N, Hv, Wv, t, stride, Ho, Wo, wp, cout, out, Ho, Wo, out_cstride, out_coff, 1, 0, 0, e);
     if (rc) return rc;
+    const bool wino = ssie_wino_eligible(p, t);
+    PackDesc pd = wino ? ssie_make_pack_wino(weight, wp, cin_w, cout, t, /*s_k*/ T, /*s_n*/ cin_w * T, 1)
+                       : ssie_make_pack(weight, wp, cin_w, cout, t, /*s_k*/ T, /*s_n*/ cin_w * T, 1);
+    if (ssie_launch_pack(pd, st)) return SSIE_E_LAUNCH;
+    if (wino) ssie_conv_to_wino(p, wp);
     if (!(p.tile_counter = take_counters(cur, end, 1, st))) return SSIE_E_WORKSPACE;
     return ssie_launch_fprop(p, st) ? SSIE_E_LAUNCH : 0;
 }
@@ -322,14 +376,17 @@ extern "C" int ssie_conv2d_dgrad(const float* g, int g_cstride, int g_coff, int 
     const float* wbase = weight + (size_t)ci_off * T;
     if (stride == 1) {
         TapList t = ssie_taps_dgrad_s1(k);
-        float* wp = ws_take(cur, end, ssie_packed_floats(cout, cs, T));
+        const size_t wf = ssie_packed_floats(cout, cs, T), uf = k == 3 ? ssie_wino_packed_floats(cout, cs) : 0;
+        float* wp = ws_take(cur, end, wf > uf ? wf : uf);
         if (!wp) return SSIE_E_WORKSPACE;
-        // OIHW: k = co -> stride cin_total*T, n = ci -> stride T
-        PackDesc pd = ssie_make_pack(wbase, wp, cout, cs, t, cin_total * T, T, 1);
-        if (ssie_launch_pack(pd, st)) return SSIE_E_LAUNCH;
         ConvParams p;
         int rc = ssie_make_conv(p, &in, 1, N, Ho, Wo, t, 1, Hin, Win, wp, cs, gx, Hin, Win, gx_cstride, gx_coff, 1, 0, 0, e);
         if (rc) return rc;
+        // OIHW: k = co -> stride cin_total*T, n = ci -> stride T
+        const bool wino = ssie_wino_eligible(p, t);
+        PackDesc pd = wino ? ssie_make_pack_wino(wbase, wp, cout, cs, t, cin_total * T, T, 1) : ssie_make_pack(wbase, wp, cout, cs, t, cin_total * T, T, 1);
+        if (ssie_launch_pack(pd, st)) return SSIE_E_LAUNCH;
+        if (wino) ssie_conv_to_wino(p, wp);
         if (!(p.tile_counter = take_counters(cur, end, 1, st))) return SSIE_E_WORKSPACE;
         return ssie_launch_fprop(p, st) ? SSIE_E_LAUNCH : 0;
     }

@@ -205,6 +205,13 @@ struct Builder {
         pl.pack_cursor = align_up(pl.pack_cursor + floats, 64);
         return r;
     }
+    // packed-weight floats of a conv launch: room for either form when the Winograd kernel may take it
+    static size_t pack_floats(int K, int N, int k, int stride)
+    {
+        const size_t a = ssie_packed_floats(K, N, k * k);
+        const size_t w = (k == 3 && stride == 1) ? ssie_wino_packed_floats(K, N) : 0;
+        return a > w ? a : w;
+    }
     SrcDesc src(const char* name, int C, int Hv, int Wv, int coff = 0)
     {
         if (h16) {
@@ -228,7 +235,7 @@ struct Builder {
         // algorithmic FLOPs: real (un-padded) channels and taps only
         const double fl = 2.0 * p.N * p.Ho * p.Wo * (double)p.Cout * k_real * p.ntaps;
         char tag[96];
-        snprintf(tag, sizeof(tag), "conv k%d->n%d taps%d si%d so%d %dx%d", k_real, p.Cout, p.ntaps, p.si, p.so, p.Ho, p.Wo);
+        snprintf(tag, sizeof(tag), "%sconv k%d->n%d taps%d si%d so%d %dx%d", p.wino ? "winograd " : "", k_real, p.Cout, p.ntaps, p.si, p.so, p.Ho, p.Wo);
         if (h16) {
             std::string t16 = std::string("bf16 ") + tag;
             ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_fprop_bf16(p, st); }, p.Cout_pad % 64 == 0 ? K_FPROP2 : K_FPROP1, fl, t16));
@@ -245,7 +252,7 @@ struct Builder {
     {
         const int T = L.k * L.k, pad = (L.k - 1) / 2;
         TapList t = ssie_taps_conv(L.k);
-        float* wp = take_pack(ssie_packed_floats(L.cin, L.cout, T));
+        float* wp = take_pack(pack_floats(L.cin, L.cout, L.k, stride));
         if (dry) return 0;
         const BufInfo& ob = pl.bi(out);
         Epilogue e; memset(&e, 0, sizeof(e)); e.bias = pl.P + L.b; e.act = act;
@@ -264,10 +271,13 @@ struct Builder {
             push(ops, p, L.cin);
             return 0;
         }
-        pl.packs.push_back(ssie_make_pack(pl.P + L.w, wp, L.cin, L.cout, t, T, L.cin * T, 1));
         int rc = ssie_make_conv(p, srcs.data(), (int)srcs.size(), pl.N, Hv, Wv, t, stride, Ho, Wo, wp, L.cout,
                                 pl.buf(out), ob.H, ob.W, ob.cs, out_coff, 1, 0, 0, e);
         if (rc) return rc;
+        if (ssie_wino_eligible(p, t)) {
+            pl.packs.push_back(ssie_make_pack_wino(pl.P + L.w, wp, L.cin, L.cout, t, T, L.cin * T, 1));
+            ssie_conv_to_wino(p, wp);
+        } else pl.packs.push_back(ssie_make_pack(pl.P + L.w, wp, L.cin, L.cout, t, T, L.cin * T, 1));
         push(ops, p, L.cin);
         return 0;
     }
@@ -316,12 +326,15 @@ struct Builder {
         const float* wbase = dry ? nullptr : pl.P + L.w + (size_t)ci_off * T;
         if (stride == 1) {
             TapList t = ssie_taps_dgrad_s1(L.k);
-            float* wp = take_pack(ssie_packed_floats(L.cout, cs, T));
+            float* wp = take_pack(pack_floats(L.cout, cs, L.k, 1));
             if (dry) return 0;
-            pl.packs.push_back(ssie_make_pack(wbase, wp, L.cout, cs, t, L.cin * T, T, 1));
             ConvParams p;
             int rc = ssie_make_conv(p, &in, 1, pl.N, gb.H, gb.W, t, 1, xb.H, xb.W, wp, cs, pl.buf(gx), xb.H, xb.W, xb.cs, 0, 1, 0, 0, e);
             if (rc) return rc;
+            if (ssie_wino_eligible(p, t)) {
+                pl.packs.push_back(ssie_make_pack_wino(wbase, wp, L.cout, cs, t, L.cin * T, T, 1));
+                ssie_conv_to_wino(p, wp);
+            } else pl.packs.push_back(ssie_make_pack(wbase, wp, L.cout, cs, t, L.cin * T, T, 1));
             push(ops, p, L.cout);
             return 0;
         }

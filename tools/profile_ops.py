@@ -31,6 +31,10 @@ def main():
     rows = [(acc[i] / reps, fl[i], kinds[i], names[i]) for i in range(n)]
     tot = sum(r[0] for r in rows)
     print(f"{n} launches, {tot:.2f} ms per step")
+    if os.environ.get("RAW"):
+        for i, (t, f, k, nm) in enumerate(rows):
+            if os.environ["RAW"] in nm:
+                print(f"  #{i:3d} {t:7.3f} ms {f / (t * 1e-3) / 1e12 if f > 0 else 0:6.1f} TF  {nm}")
     agg = {}
     for t, f, k, nm in rows:
         key = (H.Plan.KINDS[k], nm)
