@@ -278,6 +278,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                  \
                 bfr[(G) & 1][j_] = Bl[((((G) & 3) * 4 + j_) * 4 + ((G) >> 2) * 2) * 32];
             // B^T d B for transform row i of k-quad KQ -> vv[G & 1]
+#ifdef SSIE_X_NOXFORM
+#define WN_XFORM(G) { _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) vv[(G) & 1][j_] = rows[(G) >> 2][(G) & 3][j_]; }
+#else
 #define WN_XFORM(G)                                                                                           \
             {                                                                                                 \
                 constexpr int kq_ = (G) >> 2, i_ = (G) & 3;                                                   \
@@ -288,12 +291,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 vv[(G) & 1][0] = r_[0] - r_[2]; vv[(G) & 1][1] = r_[1] + r_[2];                                \
                 vv[(G) & 1][2] = r_[2] - r_[1]; vv[(G) & 1][3] = r_[1] - r_[3];                                \
             }
+#endif
+#ifdef SSIE_X_NOMFMA
+#define WN_MFMA(G) _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) acc[((G) & 3) * 4 + j_][0] += vv[(G) & 1][j_].x + bfr[(G) & 1][j_].x;
+#else
 #define WN_MFMA(G)                                                                                            \
             _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_)                                                  \
             _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                \
                 constexpr int xi0_ = ((G) & 3) * 4;                                                           \
                 acc[xi0_ + j_] = MFMA32(vv[(G) & 1][j_][c_], bfr[(G) & 1][j_][c_], acc[xi0_ + j_]);           \
             }
+#endif
             // prologue: everything group 0 needs, and the rows of group 1
             WN_LD_ROW(0, 0) WN_LD_ROW(0, 2) WN_LD_B(0) WN_LD_ROW(0, 1)
             WN_XFORM(0)
@@ -301,37 +309,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             ST_ACC(4);
             // group 0
             WN_LD_B(1) WN_LD_ROW(0, 3)
+#ifndef SSIE_X_NODMA
             WN_DMA_U(pchunk, pco0, buf ^ 1)
+#endif
             WN_XFORM(1)
             WN_MFMA(0)
             __builtin_amdgcn_sched_barrier(0);
             // group 1
             WN_LD_B(2)
+#ifndef SSIE_X_NODMA
             WN_DMA_HALO(0, pchunk, pn, pa0, pb0, buf ^ 1)
+#endif
             WN_XFORM(2)
             WN_MFMA(1)
             __builtin_amdgcn_sched_barrier(0);
             // group 2
             WN_LD_B(3) WN_LD_ROW(1, 0) WN_LD_ROW(1, 2)
+#ifndef SSIE_X_NODMA
             WN_DMA_HALO(1, pchunk, pn, pa0, pb0, buf ^ 1)
+#endif
             WN_XFORM(3)
             WN_MFMA(2)
             __builtin_amdgcn_sched_barrier(0);
             // group 3
             WN_LD_B(4) WN_LD_ROW(1, 1)
+#ifndef SSIE_X_NODMA
             WN_DMA_HALO(2, pchunk, pn, pa0, pb0, buf ^ 1)
+#endif
             WN_XFORM(4)
             WN_MFMA(3)
             __builtin_amdgcn_sched_barrier(0);
             // group 4
             WN_LD_B(5) WN_LD_ROW(1, 3)
+#ifndef SSIE_X_NODMA
             WN_DMA_HALO(3, pchunk, pn, pa0, pb0, buf ^ 1)
+#endif
             WN_XFORM(5)
             WN_MFMA(4)
             __builtin_amdgcn_sched_barrier(0);
             // group 5
             WN_LD_B(6)
+#ifndef SSIE_X_NODMA
             WN_DMA_HALO(4, pchunk, pn, pa0, pb0, buf ^ 1)
+#endif
             WN_XFORM(6)
             WN_MFMA(5)
             __builtin_amdgcn_sched_barrier(0);
@@ -379,7 +399,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     else wino_epilogue16_ragged<RQ>(p, y_, o0, rowstride, pixstride, bv, oy0, ox0);           \
                     __builtin_amdgcn_sched_barrier(0);                                                        \
                 }
+#ifdef SSIE_X_NOEPI
+                { float t_ = 0.f; _Pragma("unroll") for (int x_ = 0; x_ < 16; ++x_) t_ += acc[x_][0]; if (t_ == 123.456f) p.out[o0] = t_; }
+#else
                 WN_PASS(0) WN_PASS(1) WN_PASS(2) WN_PASS(3)
+#endif
 #undef WN_PASS
             }
         }
@@ -398,12 +422,316 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef WN_DECODE
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// conv_wino8_kernel: the same algorithm with TWO waves per SIMD.  One workgroup = 8 waves = the same 16 x 32 positions x 32
+// channels, but the MFMA is v_mfma_f32_16x16x4_f32: wave w owns Winograd tile row w (16 tiles = M) x both 16-channel halves (N)
+// x all 16 xi = 32 accumulator tiles of 4 registers = 128 registers, so two waves fit a SIMD and each one's LDS reads, input
+// transform, DMA address arithmetic and epilogue run underneath the other's MFMAs (measured on the one-wave kernel: MFMA time
+// and everything-else time ADD when a SIMD has a single wave, tools/build_variants.py ablations).
+//   A operand (16 tiles x 4 k): lane l = tile column l%16, k-group g = l/16 = channel quad g of the chunk; the 4 components of the
+//   lane's float4 are the 4 MFMAs of a (xi, N-half).   B operand: lane = channel l%16 of the half, same quad g.
+//   D (16 x 16): lane l = channel l%16, registers r = tile columns 4g + r.
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// packed fp32 add / subtract
+// as inline asm: hipcc splits float2 additions whose lanes are consumed one by one (by the MFMAs) into two v_add_f32, and every
+// VALU instruction costs MFMA time here.  The hazard recognizer does not see an asm as a VALU write, so the values pass through
+// PK_FENCE (one s_nop covering the VALU-write -> MFMA-read wait states) before the first MFMA reads them.
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#define PK_FENCE8(a, b, c, d, e, f, g, h) asm volatile("s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h))
+
+namespace {
+// 16 outputs of one lane = (tile column 4g + r, r = k&3) x (pixel e = k>>2 of the 2 x 2 tile), one channel; o0 includes 8g pixels
+#define W8_EOFF(k) ((long)((k) >> 3) * rowstride + (long)(2 * ((k) & 3) + (((k) >> 2) & 1)) * pixstride)
+template <typename PT>
+__device__ __forceinline__ void wino8_epilogue16(const PT& p, float v[16], size_t o0, long rowstride, long pixstride, float bv)
+{
+    if (p.act == ACT_RELU) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = fmaxf(v[k] + bv, 0.f);
+    } else if (p.act == ACT_SIGMOID) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = 1.f / (1.f + expf(-(v[k] + bv)));
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] += bv;
+    }
+    if (p.mask_mode != MASK_NONE) {
+        const float* mp = p.mask_y + o0;
+        float y[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) y[k] = mp[W8_EOFF(k)];
+        if (p.mask_mode == MASK_RELU) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = y[k] > 0.f ? v[k] : 0.f;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] *= y[k] * (1.f - y[k]);
+        }
+    }
+    if (p.out2) {
+        float* o2 = p.out2 + o0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) o2[W8_EOFF(k)] = v[k];
+    }
+    if (p.addsrc) {
+        const float* ap = p.addsrc + o0;
+        float a[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[k] = ap[W8_EOFF(k)];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] += a[k];
+    }
+    float* ob = p.out + o0;
+    if (p.accumulate) {
+        float a[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[k] = ob[W8_EOFF(k)];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] += a[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) ob[W8_EOFF(k)] = v[k];
+}
+
+template <typename PT>
+__device__ __forceinline__ void wino8_epilogue16_ragged(const PT& p, const float v[16], size_t o0, long rowstride, long pixstride, float bv,
+                                                        int oy, int ox)
+{
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int y = oy + (k >> 3), x = ox + 2 * (k & 3) + ((k >> 2) & 1);
+        if (y >= p.Hout || x >= p.Wout) continue;
+        const size_t o = o0 + W8_EOFF(k);
+        float t = v[k] + bv;
+        if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
+        else if (p.act == ACT_SIGMOID) t = 1.f / (1.f + expf(-t));
+        if (p.mask_mode == MASK_RELU) t = p.mask_y[o] > 0.f ? t : 0.f;
+        else if (p.mask_mode == MASK_SIGMOID) { const float yy = p.mask_y[o]; t *= yy * (1.f - yy); }
+        if (p.out2) p.out2[o] = t;
+        if (p.addsrc) t += p.addsrc[o];
+        if (p.accumulate) t += p.out[o];
+        p.out[o] = t;
+    }
+}
+}  // namespace
+
+template <bool SINGLE, bool UP>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino8_kernel(const ConvParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    constexpr int NTHR = 512;
+    f32x4* As0 = (f32x4*)smem_f;                    // [2][W_HPB]
+    f32x4* Bs0 = As0 + 2 * W_HPB;                   // [2][W_BSZ]
+    int* s_next = (int*)(Bs0 + 2 * W_BSZ);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, tx = lane & 15;
+    // halo buffer layout as in conv_wino_kernel; this lane's tile = (row `wave`, column tx), its channel quad = g
+    const int abase = ((2 * wave) * (W_HPW / 2) + tx + g * W_PLANE) * 16;
+    const int nsteps = p.nchunks;
+    const int total_tiles = p.N * p.tiles_y * p.tiles_x * p.co_blocks;
+
+#define W8_DECODE(T, N_, A0_, B0_, CO0_)                                                  \
+    {                                                                                     \
+        int q_ = (T);                                                                     \
+        CO0_ = (q_ % p.co_blocks) * 32; q_ /= p.co_blocks;                                \
+        B0_ = (q_ % p.tiles_x) * W_TW; q_ /= p.tiles_x;                                   \
+        A0_ = (q_ % p.tiles_y) * W_TH; N_ = q_ / p.tiles_y;                               \
+    }
+    // DMA of one step's operands: 4 pieces of U and 5 halo slots per lane.  VALU instructions and MFMAs SHARE a SIMD's issue slot on
+    // this chip (tools/coexec_bench.hip: every v_add between two MFMAs costs its 4 cycles, with one or two waves per SIMD), so
+    // the per-slot address arithmetic is kept minimal: a per-lane table in LDS holds, for each of the lane's 5 slots,
+    //   halo pixel offset hy*Wv + hx (15 bits) | channel quad j << 15 | hy << 17 | hx << 22      (hy = 31: padding slot)
+    // and a step only adds the scalar tile base and compares hy / hx / j against scalar ranges.  (UP variants: sources of
+    // different sizes, decoded arithmetically as in conv_wino_kernel.)
+    int* dma_tab = s_next + 4;                      // [W_HPB / NTHR][NTHR]
+    if (!UP) {
+#pragma unroll
+        for (int i = 0; i < W_HPB / NTHR; ++i) {
+            const int id = i * NTHR + tid;
+            const int j = (id >= W_PLANE) + (id >= 2 * W_PLANE) + (id >= 3 * W_PLANE), r = id - j * W_PLANE;
+            const int par = r >= W_HALF, rr = r - par * W_HALF;
+            const int hy = r < 2 * W_HALF ? (rr * 241) >> 12 : 31;
+            const int hx = r < 2 * W_HALF ? 2 * (rr - hy * (W_HPW / 2)) + par : 0;
+            dma_tab[i * NTHR + tid] = (r < 2 * W_HALF ? hy * p.Wv + hx : 0) | (j << 15) | (hy << 17) | (hx << 22);
+        }
+    }
+#ifdef SSIE_X_NOTAB
+#define W8_NOTAB 1
+#else
+#define W8_NOTAB 0
+#endif
+#define W8_PREFETCH(CHUNK, N_, A0_, B0_, CO0_, BUF)                                                           \
+    {                                                                                                         \
+        const f32x4* wsrc_ = (const f32x4*)p.wpacked + (size_t)(CHUNK) * 64 * p.Cout_pad + (CO0_);            \
+        f32x4* bbuf_ = Bs0 + (BUF) * W_BSZ;                                                                   \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                    \
+            const int pc_ = q_ * 8 + wave;                        /* piece = two (xi, q) rows of 32 float4 */   \
+            GLDS16(wsrc_ + (unsigned)((pc_ * 2 + (lane >> 5)) * p.Cout_pad + (lane & 31)), bbuf_ + pc_ * 64); \
+        }                                                                                                     \
+        const SrcSel s_ = SINGLE ? ssie_only_src(p) : ssie_pick_src(p, (CHUNK) * SSIE_CK);                    \
+        const int vy0_ = (A0_) - 1, vx0_ = (B0_) - 1;                                                         \
+        f32x4* abuf_ = As0 + (BUF) * W_HPB;                                                                   \
+        if (UP || W8_NOTAB) {                                                                                 \
+            _Pragma("unroll") for (int i_ = 0; i_ < W_HPB / NTHR; ++i_) {                                     \
+                const int id_ = i_ * NTHR + tid;                                                              \
+                const int j_ = (id_ >= W_PLANE) + (id_ >= 2 * W_PLANE) + (id_ >= 3 * W_PLANE), r_ = id_ - j_ * W_PLANE; \
+                const int par_ = r_ >= W_HALF, rr_ = r_ - par_ * W_HALF;                                      \
+                const int hy_ = r_ < 2 * W_HALF ? (rr_ * 241) >> 12 : 255;                                    \
+                const int hx_ = 2 * (rr_ - hy_ * (W_HPW / 2)) + par_;                                         \
+                const f32x4* g_ = wino_virtual_addr<UP>(s_, (N_), vy0_ + hy_, vx0_ + hx_,                     \
+                                                        p.Hv, p.Wv, (CHUNK) * SSIE_CK + 4 * j_ - s_.cbeg);    \
+                GLDS16(g_, abuf_ + i_ * NTHR + wave * 64);                                                    \
+            }                                                                                                 \
+        } else {                                                                                              \
+            const int c0_ = (CHUNK) * SSIE_CK - s_.cbeg;                                                      \
+            const int tb_ = (((N_) * p.Hv + vy0_) * p.Wv + vx0_) * s_.cstride + s_.coff + c0_;                \
+            const unsigned ylo_ = max(0, -vy0_), yn_ = min(W_HPH, p.Hv - vy0_) - ylo_;                        \
+            const unsigned xlo_ = max(0, -vx0_), xn_ = min(W_HPW, p.Wv - vx0_) - xlo_;                        \
+            const int jn_ = (s_.C - c0_ + 3) >> 2;                                                            \
+            const unsigned long long zp_ = (unsigned long long)wino_zero_page;                                \
+            _Pragma("unroll") for (int i_ = 0; i_ < W_HPB / NTHR; ++i_) {                                     \
+                const unsigned e_ = (unsigned)dma_tab[i_ * NTHR + tid];                                       \
+                const unsigned hy_ = (e_ >> 17) & 31, hx_ = e_ >> 22, j_ = (e_ >> 15) & 3;                    \
+                const bool ok_ = hy_ - ylo_ < yn_ && hx_ - xlo_ < xn_ && (int)j_ < jn_;                       \
+                const int off_ = tb_ + (int)(e_ & 0x7fff) * s_.cstride + 4 * (int)j_;                         \
+                const unsigned long long a_ = (unsigned long long)(s_.ptr + off_), m_ = ok_ ? ~0ull : 0ull;    \
+                GLDS16((const f32x4*)((a_ & m_) | (zp_ & ~m_)), abuf_ + i_ * NTHR + wave * 64);               \
+            }                                                                                                 \
+        }                                                                                                     \
+    }
+
+    int tile = blockIdx.x;
+    if (tile >= total_tiles) return;
+    int n, a0, b0, co0;
+    W8_DECODE(tile, n, a0, b0, co0)
+    int gstep = 0;
+    W8_PREFETCH(0, n, a0, b0, co0, 0)
+    int fetched = 0x7fffffff;
+
+    while (tile < total_tiles) {
+        f32x4 acc[16][2];
+#pragma unroll
+        for (int x = 0; x < 16; ++x)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[x][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float bv[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) bv[c] = (p.bias && co0 + 16 * c + tx < p.Cout) ? p.bias[co0 + 16 * c + tx] : 0.f;
+        int ntile = 0x7fffffff;
+        int nn = n, na0 = a0, nb0 = b0, nco0 = co0;
+
+        for (int step = 0; step < nsteps; ++step, ++gstep) {
+            const int buf = gstep & 1;
+            if (tid == 0) {
+                if (nsteps == 1 || !p.tile_counter) {
+                    if (step == 0) *s_next = p.tile_counter ? (int)gridDim.x + atomicAdd(p.tile_counter, 1) : tile + (int)gridDim.x;
+                } else if (step == 1) *s_next = fetched;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (step == (nsteps > 1 ? 1 : 0)) {
+                ntile = *s_next;
+                if (ntile < total_tiles) W8_DECODE(ntile, nn, na0, nb0, nco0)
+            }
+            const char* Ab = (const char*)(As0 + buf * W_HPB) + abase;
+            const f32x4* Bl = Bs0 + buf * W_BSZ + g * 32 + tx;
+            // the 4 x 4 patch of this lane's tile, channel quad g -> B^T d B, one transform row at a time; the additions are written
+            // on float2 halves so that they compile to v_pk_add_f32 (half the VALU instructions)
+            f32x2 d[4][4][2];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const f32x4 t = *(const f32x4*)(Ab + ((a * (W_HPW / 2) + (b >> 1)) + (b & 1) * W_HALF) * 16);
+                    d[a][b][0] = f32x2{t.x, t.y}; d[a][b][1] = f32x2{t.z, t.w};
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x2 r[4][2], v[4][2];
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh)
+                        r[b][hh] = i == 0 ? pk_sub(d[0][b][hh], d[2][b][hh]) : i == 1 ? pk_add(d[1][b][hh], d[2][b][hh])
+                                 : i == 2 ? pk_sub(d[2][b][hh], d[1][b][hh]) : pk_sub(d[1][b][hh], d[3][b][hh]);
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    v[0][hh] = pk_sub(r[0][hh], r[2][hh]); v[1][hh] = pk_add(r[1][hh], r[2][hh]);
+                    v[2][hh] = pk_sub(r[2][hh], r[1][hh]); v[3][hh] = pk_sub(r[1][hh], r[3][hh]);
+                }
+                PK_FENCE8(v[0][0], v[0][1], v[1][0], v[1][1], v[2][0], v[2][1], v[3][0], v[3][1]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int xi = i * 4 + j;
+                    const f32x4 bf0 = Bl[(xi * 4) * 32], bf1 = Bl[(xi * 4) * 32 + 16];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        acc[xi][0] = MFMA16(v[j][c >> 1][c & 1], bf0[c], acc[xi][0]);
+                        acc[xi][1] = MFMA16(v[j][c >> 1][c & 1], bf1[c], acc[xi][1]);
+                    }
+                }
+                // the next step's DMA is issued AFTER the first transform row's MFMAs: right behind the barrier all 8 waves would
+                // do address arithmetic (VALU = no MFMA) while the matrix pipe has nothing queued yet
+                if (i == 0) {
+                    const bool more = step + 1 < nsteps;
+                    if (more) W8_PREFETCH(step + 1, n, a0, b0, co0, buf ^ 1)
+                    else if (ntile < total_tiles) W8_PREFETCH(0, nn, na0, nb0, nco0, buf ^ 1)
+                }
+            }
+            if (tid == 0 && step == 0 && nsteps > 1 && p.tile_counter)
+                fetched = (int)gridDim.x + atomicAdd(p.tile_counter, 1);
+        }
+
+        // output transform (lane-local) + epilogue: one pass of 16 outputs per 16-channel half
+        {
+            const long rowstride = (long)p.Wout * p.out_cstride, pixstride = p.out_cstride;
+            const int oy0 = a0 + 2 * wave, ox0 = b0 + 8 * g;
+            const bool full = a0 + W_TH <= p.Hout && b0 + W_TW <= p.Wout;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int co = co0 + 16 * c + tx;
+                if (co >= p.Cout) continue;
+                float y[16];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float s0[4], s1[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        s0[i] = acc[i * 4 + 0][c][r] + acc[i * 4 + 1][c][r] + acc[i * 4 + 2][c][r];
+                        s1[i] = acc[i * 4 + 1][c][r] - acc[i * 4 + 2][c][r] - acc[i * 4 + 3][c][r];
+                    }
+                    y[0 + r] = s0[0] + s0[1] + s0[2]; y[4 + r] = s1[0] + s1[1] + s1[2];
+                    y[8 + r] = s0[1] - s0[2] - s0[3]; y[12 + r] = s1[1] - s1[2] - s1[3];
+                }
+                const size_t o0 = ((size_t)(n * p.Hout + oy0) * p.Wout + ox0) * p.out_cstride + p.out_coff + co;
+                if (full) wino8_epilogue16(p, y, o0, rowstride, pixstride, bv[c]);
+                else wino8_epilogue16_ragged(p, y, o0, rowstride, pixstride, bv[c], oy0, ox0);
+            }
+        }
+        n = nn; a0 = na0; b0 = nb0; co0 = nco0; tile = ntile;
+    }
+#undef W8_PREFETCH
+#undef W8_DECODE
+}
+
+template __global__ void conv_wino8_kernel<false, false>(const ConvParams);
+template __global__ void conv_wino8_kernel<true, false>(const ConvParams);
+template __global__ void conv_wino8_kernel<false, true>(const ConvParams);
+template __global__ void conv_wino8_kernel<true, true>(const ConvParams);
+
 template __global__ void conv_wino_kernel<false, false>(const ConvParams);
 template __global__ void conv_wino_kernel<true, false>(const ConvParams);
 template __global__ void conv_wino_kernel<false, true>(const ConvParams);
 template __global__ void conv_wino_kernel<true, true>(const ConvParams);
 
-size_t ssie_wino_lds_bytes() { return (size_t)(2 * W_HPB + 2 * W_BSZ) * 16 + 64; }
+int ssie_wino_waves8 = 1;      // A/B switch: 1 = conv_wino8_kernel (two waves per SIMD), 0 = conv_wino_kernel (one)
+extern "C" void ssie_debug_set_wino_waves8(int v) { ssie_wino_waves8 = v; }
+
+size_t ssie_wino_lds_bytes() { return (size_t)(2 * W_HPB + 2 * W_BSZ) * 16 + 64 + (size_t)W_HPB * 4; }
 
 int ssie_launch_fprop_wino(const ConvParams& p, hipStream_t st)
 {
@@ -419,6 +747,18 @@ int ssie_launch_fprop_wino(const ConvParams& p, hipStream_t st)
     const size_t lds = ssie_wino_lds_bytes();
     bool up = false;
     for (int s = 0; s < p.nsrc; ++s) up = up || p.src[s].sy != 1.f || p.src[s].sx != 1.f;
+    if (ssie_wino_waves8) {
+        static unsigned seen8[4] = {0, 0, 0, 0};
+        ssie_allow_full_lds((const void*)conv_wino8_kernel<false, false>, seen8[0]);
+        ssie_allow_full_lds((const void*)conv_wino8_kernel<true, false>, seen8[1]);
+        ssie_allow_full_lds((const void*)conv_wino8_kernel<false, true>, seen8[2]);
+        ssie_allow_full_lds((const void*)conv_wino8_kernel<true, true>, seen8[3]);
+        if (p.nsrc == 1 && !up) hipLaunchKernelGGL((conv_wino8_kernel<true, false>), grid, dim3(512), lds, st, p);
+        else if (p.nsrc == 1) hipLaunchKernelGGL((conv_wino8_kernel<true, true>), grid, dim3(512), lds, st, p);
+        else if (!up) hipLaunchKernelGGL((conv_wino8_kernel<false, false>), grid, dim3(512), lds, st, p);
+        else hipLaunchKernelGGL((conv_wino8_kernel<false, true>), grid, dim3(512), lds, st, p);
+        return hipGetLastError() == hipSuccess ? 0 : 34;
+    }
     if (p.nsrc == 1 && !up) hipLaunchKernelGGL((conv_wino_kernel<true, false>), grid, dim3(256), lds, st, p);
     else if (p.nsrc == 1) hipLaunchKernelGGL((conv_wino_kernel<true, true>), grid, dim3(256), lds, st, p);
     else if (!up) hipLaunchKernelGGL((conv_wino_kernel<false, false>), grid, dim3(256), lds, st, p);

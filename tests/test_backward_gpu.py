@@ -138,18 +138,23 @@ def check_chain(H, case, n, bands, h, w, coefs, forced=None):
     assert not bad, "backward-chain parity failures:\n" + "\n".join(bad)
 
 
-@pytest.fixture(params=[None, "dma_kernels"])
+@pytest.fixture(params=[None, "dma_kernels", "winograd"])
 def forced_kernels(pkg, request):
     """None = launch heuristics (8x16 tiles at these small batches); "dma_kernels" = the kernels the bench-size layers
-    run (16x16 / 16x32 DMA tiles, split 32-channel workgroups) forced through the same cases (include/ssie_debug.h)."""
+    run (16x16 / 16x32 DMA tiles, split 32-channel workgroups) forced through the same cases (include/ssie_debug.h);
+    "winograd" = the Winograd F(2x2,3x3) kernel for every stride-1 3x3 forward / data-gradient launch."""
     L = pkg.lib()
-    if request.param:
+    if request.param == "winograd":               # every stride-1 3x3 forward / data-gradient launch on conv_wino8_kernel (F(2x2,3x3))
+        L.ssie_debug_set_wino_min_tiles(1)
+    elif request.param:
+        L.ssie_debug_set_wino_min_tiles(1 << 30)
         L.ssie_debug_set_fprop_min_tiles16(0)
         L.ssie_debug_set_fprop_wide_min_tiles(1)
         L.ssie_debug_set_fprop_v2_split_min_tiles(1)
         L.ssie_debug_set_skinny_final(0)          # and final_conv (64 -> 1) on the MFMA tiles instead of the VALU kernels
         L.ssie_debug_set_spectral9(0)             # and the 9 x 9 convolution on the direct MFMA kernels instead of the frequency domain
     yield request.param
+    L.ssie_debug_set_wino_min_tiles(256)
     L.ssie_debug_set_skinny_final(1)
     L.ssie_debug_set_spectral9(1)
     L.ssie_debug_set_fprop_min_tiles16(256)

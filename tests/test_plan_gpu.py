@@ -56,19 +56,23 @@ def rel_l2(a, b):
     return (a.double() - b.double()).norm().item() / max(b.double().norm().item(), 1e-30)
 
 
-@pytest.fixture(params=[None, "dma_kernels"])
+@pytest.fixture(params=[None, "dma_kernels", "winograd"])
 def forced_kernels(pkg, request):
     """None = launch heuristics (8x16 tiles at these small batches).  "dma_kernels" forces the kernels the bench-size
     layers run - 16x16 and, where eligible, 16x32 tiles (conv_fprop_v2_kernel / conv_fprop_v2w_kernel) - through the same
     parity cases, so the whole fwd + bwd chain is checked on them too."""
     L = pkg[0].lib()
-    if request.param:
+    if request.param == "winograd":               # every stride-1 3x3 forward / data-gradient launch on conv_wino8_kernel (F(2x2,3x3))
+        L.ssie_debug_set_wino_min_tiles(1)
+    elif request.param:
         L.ssie_debug_set_fprop_min_tiles16(0)
         L.ssie_debug_set_fprop_wide_min_tiles(1)
         L.ssie_debug_set_fprop_v2_split_min_tiles(1)
+        L.ssie_debug_set_wino_min_tiles(1 << 30)  # (the Winograd kernel is forced in its own fixture value below)
         L.ssie_debug_set_skinny_final(0)          # and final_conv (64 -> 1) on the MFMA tiles instead of the VALU kernels
         L.ssie_debug_set_spectral9(0)             # and the 9 x 9 convolution on the direct MFMA kernels instead of the frequency domain
     yield request.param
+    L.ssie_debug_set_wino_min_tiles(256)
     L.ssie_debug_set_skinny_final(1)
     L.ssie_debug_set_spectral9(1)
     L.ssie_debug_set_fprop_min_tiles16(256)
@@ -99,10 +103,12 @@ def test_stagewise_parity(pkg, case, forced_kernels):
 
     # Every parameter gradient is a linear functional of the loss cotangents, and those carry the sg() flip noise directly
     # (d/dD below: 2-7e-2 in BOTH fp32 evaluations).  One fp32 oracle run gives a noisy per-tensor estimate of how much of
-    # it survives the averaging into a deep-layer gradient, so the floor is tied to the cotangent noise itself: a tenth
-    # of the fp32 oracle's own d/dD deviation (never below 1e-3).
+    # it survives the averaging into a deep-layer gradient, so the floor is tied to the cotangent noise itself: 0.15 x
+    # the fp32 oracle's own d/dD deviation (never below 1e-3; which signs flip differs between two valid fp32 forwards - direct,
+    # frequency-domain and Winograd convolutions - and the worst tensor seen is 0.102 x).  The noise-free pin of the same
+    # launches is tests/test_backward_gpu.py (fixed 2e-5).
     noise_D = rel_l2(tr32["D"].grad, tr["D"].grad)
-    floor = max(GRAD_FLOOR.get(case, 1e-3), 0.1 * noise_D)
+    floor = max(GRAD_FLOOR.get(case, 1e-3), 0.15 * noise_D)
 
     def gtol(ref32, ref64):
         return max(floor, 2.0 * rel_l2(ref32, ref64))
