@@ -24,7 +24,7 @@ namespace {
 
 typedef std::function<int(hipStream_t)> FnT;
 // op kinds for per-kernel-class profiling (bench.py roofline): see ssie_plan_profile_step
-enum { K_FPROP2 = 0, K_FPROP1, K_WGRAD, K_WGRAD_REDUCE, K_COLSUM, K_PACK, K_LOSS, K_FFT, K_ATTN, K_ELEMENTWISE, K_SPEC, K_NKINDS };
+enum { K_FPROP2 = 0, K_FPROP1, K_WGRAD, K_WGRAD_REDUCE, K_COLSUM, K_PACK, K_LOSS, K_FFT, K_ATTN, K_ELEMENTWISE, K_SPEC, K_WINO, K_NKINDS };
 struct Fn {
     FnT fn; int kind; double flops; std::string tag;
     int slab = 0;       // K_WGRAD / K_WGRAD_REDUCE: which of the two slab areas the launch writes / reads
@@ -241,7 +241,7 @@ struct Builder {
             ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_fprop_bf16(p, st); }, p.Cout_pad % 64 == 0 ? K_FPROP2 : K_FPROP1, fl, t16));
             return;
         }
-        ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_fprop(p, st); }, p.Cout_pad % 64 == 0 ? K_FPROP2 : K_FPROP1, fl, tag));
+        ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_fprop(p, st); }, p.wino ? K_WINO : p.Cout_pad % 64 == 0 ? K_FPROP2 : K_FPROP1, fl, tag));
     }
     // bf16 list: which outputs stay fp32 (API outputs and the attention operands)
     static bool out_is_f32(const char* out) { return !strcmp(out, "RL_1") || !strcmp(out, "qkv") || !strcmp(out, "D"); }
@@ -957,8 +957,8 @@ extern "C" int ssie_plan_backward_from_cotangents(void* h, void* stream)
 }
 
 // one full compute_loss + backward with a HIP event after every launch: per-kernel-class device time and
-// algorithmic FLOPs of that step (synchronises).  ms/flops/counts have K_NKINDS = 10 entries:
-// {fprop<64>, fprop<32>, wgrad, wgrad_reduce, colsum, pack, loss, fft, attention, elementwise}
+// algorithmic FLOPs of that step (synchronises).  ms/flops/counts have K_NKINDS = SSIE_NKINDS entries (include/ssie_hip.h);
+// a Winograd launch is counted with the FLOPs of the direct convolution it replaces (it executes 16/36 of them)
 extern "C" int ssie_plan_profile_step(void* h, const float* x, const long* strides4, void* stream,
                                       double* ms, double* flops, int* counts)
 {
