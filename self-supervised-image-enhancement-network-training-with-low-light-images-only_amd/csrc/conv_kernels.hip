@@ -580,7 +580,7 @@ template __global__ void conv_wgrad_kernel<32, 64, 9, 4>(const WgradParams);
 // 64 output quads x 4 slice groups per block, fixed summation order (deterministic, identical on every rank).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int nslices, int ntaps, int ci_pad, int co_pad,
                                     int Cin, int Cout, float* __restrict__ dst, long s_co, long s_ci, long s_t,
-                                    const float* __restrict__ bias_slabs, float* __restrict__ db, int accumulate)
+                                    const float* __restrict__ bias_slabs, float* __restrict__ db, int accumulate, int accumulate_bias)
 {
     __shared__ f32x4 red[4][64];
     const int lo = threadIdx.x & 63, sg = threadIdx.x >> 6;
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         for (int k = 0; k < 4; ++k) {
             if (co + k >= Cout) break;
             float* d = is_w ? dst + (co + k) * s_co + ci * s_ci + t * s_t : db + co + k;
-            *d = accumulate ? (*d + tot[k]) : tot[k];
+            *d = (is_w ? accumulate : accumulate_bias) ? (*d + tot[k]) : tot[k];
         }
     }
 }
@@ -874,6 +874,7 @@ static int wgrad_window_kind(const WgradParams& p)
 // cib/cob chosen by the caller through ci_pad/ci_blocks (ci_pad = ci_blocks*CIB)
 int ssie_launch_wgrad(const WgradParams& p, hipStream_t st)
 {
+    if (p.wino) return ssie_launch_wgrad_wino(p, st);
     const int cib = p.ci_pad / p.ci_blocks, cob = p.co_pad / p.co_blocks;
     const bool one = p.ntaps == 1;
     const int sw = wgrad_window_kind(p);
@@ -901,12 +902,13 @@ int ssie_launch_wgrad(const WgradParams& p, hipStream_t st)
 
 int ssie_launch_wgrad_reduce(const float* slabs, int nslices, int ntaps, int ci_pad, int co_pad, int Cin, int Cout,
                              float* dst, long s_co, long s_ci, long s_t, const float* bias_slabs, float* db,
-                             int accumulate, hipStream_t st)
+                             int accumulate, hipStream_t st, int accumulate_bias)
 {
     const long cq = (Cout + 3) / 4;
     long total = (long)ntaps * Cin * cq + (bias_slabs ? cq : 0);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st,
-                       slabs, nslices, ntaps, ci_pad, co_pad, Cin, Cout, dst, s_co, s_ci, s_t, bias_slabs, db, accumulate);
+                       slabs, nslices, ntaps, ci_pad, co_pad, Cin, Cout, dst, s_co, s_ci, s_t, bias_slabs, db, accumulate,
+                       accumulate_bias < 0 ? accumulate : accumulate_bias);
     return hipGetLastError() == hipSuccess ? 0 : 25;
 }
 

@@ -217,6 +217,10 @@ PackDesc ssie_make_pack_bf16(const float* w, float* dst, int K, int N, const Tap
 }
 
 extern int ssie_wgrad_rows2, ssie_wgrad_sliding;
+int ssie_wgrad_wino = 1;              // A/B switch: 1 = stride-1 3x3 weight gradients on Winograd F(3x3,2x2) (conv_wgrad_wino.hip)
+int ssie_wgrad_wino_min_tiles = 256;  // ... when the launch has at least this many 8 x 16 position tiles (tests set 1)
+extern "C" void ssie_debug_set_wgrad_wino(int v) { ssie_wgrad_wino = v; }
+extern "C" void ssie_debug_set_wgrad_wino_min_tiles(int v) { ssie_wgrad_wino_min_tiles = v; }
 int ssie_make_wgrad(WgradParams& p, const SrcDesc& src, int N, int Hv, int Wv, int ci0_weight,
                     const float* g, int g_cstride, int g_coff, int Cout, int Ho, int Wo, int si,
                     const TapList& t, float* slabs, int target_wgs)
@@ -242,6 +246,12 @@ int ssie_make_wgrad(WgradParams& p, const SrcDesc& src, int N, int Hv, int Wv, i
     if (p.rows2) p.tap_groups = ssie_ceil_div(p.tap_groups, 2);
     p.tiles_y = ssie_ceil_div(Ho, p.th); p.tiles_x = ssie_ceil_div(Wo, SSIE_TW);
     p.tiles_total = N * p.tiles_y * p.tiles_x;
+    // Winograd F(3x3,2x2): full 3 x 3 in forward tap order, stride 1, same-size output, source read 1:1; one workgroup per CU
+    // (256 accumulator registers per wave), so half the slices of the direct kernel
+    p.wino = ssie_wgrad_wino && taps_are_3x3(t) && si == 1 && Ho == Hv && Wo == Wv && src.sy == 1.f && src.sx == 1.f &&
+             src.Hs == Hv && src.Ws == Wv && p.tiles_total >= ssie_wgrad_wino_min_tiles;
+    for (int i = 0; p.wino && i < 9; ++i) if (t.dy[i] != i / 3 - 1 || t.dx[i] != i % 3 - 1) p.wino = 0;
+    if (p.wino) { p.tap_groups = 1; p.rows2 = 0; target_wgs = (target_wgs + 1) / 2; }
     int per = p.ci_blocks * p.co_blocks * p.tap_groups;
     int ns = target_wgs / per; if (ns < 1) ns = 1; if (ns > p.tiles_total) ns = p.tiles_total;
     p.nslices = ns;
@@ -249,7 +259,7 @@ int ssie_make_wgrad(WgradParams& p, const SrcDesc& src, int N, int Hv, int Wv, i
     return 0;
 }
 
-size_t ssie_wgrad_slab_floats(const WgradParams& p) { return (size_t)p.nslices * p.ntaps * p.ci_pad * p.co_pad; }
+size_t ssie_wgrad_slab_floats(const WgradParams& p) { return (size_t)p.nslices * (p.wino ? 16 : p.ntaps) * p.ci_pad * p.co_pad; }
 
 // ---------------------------------------------------------------------------------------------
 // granular C-ABI
@@ -429,6 +439,15 @@ int ssie_run_wgrad(const SrcDesc& x, int x_creal, int N, int Hv, int Wv, const f
     if (need + bneed > slab_cap_floats) return SSIE_E_WORKSPACE;
     p.bias_slabs = db ? slabs + need : nullptr;
     if (ssie_launch_wgrad(p, st)) return SSIE_E_LAUNCH;
+    if (p.wino) {
+        // slabs -> dU[16][ci][co] (fixed-order sum over the slices) -> the nine taps
+        const size_t du_floats = (size_t)16 * x_creal * gC;
+        if (need + bneed + du_floats > slab_cap_floats) return SSIE_E_WORKSPACE;
+        float* du = slabs + need + bneed;
+        if (ssie_launch_wgrad_reduce(slabs, p.nslices, 16, p.ci_pad, p.co_pad, x_creal, gC, du, 1, gC, (long)x_creal * gC,
+                                     p.bias_slabs, db, 0, st, accumulate)) return SSIE_E_LAUNCH;
+        return ssie_launch_wgrad_wino_out(du, x_creal, gC, dw, s_co, s_ci, s_t, accumulate, st) ? SSIE_E_LAUNCH : 0;
+    }
     if (ssie_launch_wgrad_reduce(slabs, p.nslices, p.ntaps, p.ci_pad, p.co_pad, x_creal, gC, dw, s_co, s_ci, s_t,
                                  p.bias_slabs, db, accumulate, st)) return SSIE_E_LAUNCH;
     return 0;

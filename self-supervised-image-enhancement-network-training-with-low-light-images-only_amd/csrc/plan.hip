@@ -24,7 +24,7 @@ namespace {
 
 typedef std::function<int(hipStream_t)> FnT;
 // op kinds for per-kernel-class profiling (bench.py roofline): see ssie_plan_profile_step
-enum { K_FPROP2 = 0, K_FPROP1, K_WGRAD, K_WGRAD_REDUCE, K_COLSUM, K_PACK, K_LOSS, K_FFT, K_ATTN, K_ELEMENTWISE, K_SPEC, K_WINO, K_NKINDS };
+enum { K_FPROP2 = 0, K_FPROP1, K_WGRAD, K_WGRAD_REDUCE, K_COLSUM, K_PACK, K_LOSS, K_FFT, K_ATTN, K_ELEMENTWISE, K_SPEC, K_WINO, K_WGRAD_WINO, K_NKINDS };
 struct Fn {
     FnT fn; int kind; double flops; std::string tag;
     int slab = 0;       // K_WGRAD / K_WGRAD_REDUCE: which of the two slab areas the launch writes / reads
@@ -368,8 +368,17 @@ struct Builder {
         p.bias_slabs = bslab;
         const double fl = 2.0 * pl.N * nbatch * Ho * Wo * (double)cout * creal * T;
         char tag[96];
-        snprintf(tag, sizeof(tag), "wgrad ci%d co%d taps%d si%d %dx%d slices%d", creal, cout, T, stride, Ho, Wo, p.nslices);
-        ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_wgrad(p, st); }, K_WGRAD, fl, tag, sl));
+        snprintf(tag, sizeof(tag), "%swgrad ci%d co%d taps%d si%d %dx%d slices%d", p.wino ? "winograd " : "", creal, cout, T, stride, Ho, Wo, p.nslices);
+        ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_wgrad(p, st); }, p.wino ? K_WGRAD_WINO : K_WGRAD, fl, tag, sl));
+        if (p.wino) {
+            // slabs -> dU[16][ci][co] (fixed-order sum over the slices; the fused bias gradient goes straight to its place) -> 9 taps
+            const size_t bneed = with_bias ? (size_t)p.nslices * p.co_pad : 0;
+            if (need + bneed + (size_t)16 * creal * cout > pl.slab_cap) return SSIE_E_WORKSPACE;
+            float* du = pl.ws + soff + need + bneed;
+            ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, p.nslices, 16, p.ci_pad, p.co_pad, creal, cout, du, 1, cout, (long)creal * cout, bslab, db, 0, st, 1); }, K_WGRAD_REDUCE, 0.0, "", sl));
+            ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_wino_out(du, creal, cout, dw, s_co, T, 1, 1, st); }, K_WGRAD_REDUCE, 0.0, "winograd wgrad: taps", sl));
+            return 0;
+        }
         ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, p.nslices, p.ntaps, p.ci_pad, p.co_pad, creal, cout, dw, s_co, T, 1, bslab, db, 1, st); }, K_WGRAD_REDUCE, 0.0, "", sl));
         return 0;
     }

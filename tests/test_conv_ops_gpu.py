@@ -29,12 +29,14 @@ def kernel_mode(H, request):
     the other three modes keep it off so the direct kernels stay covered."""
     L = H.lib()
     L.ssie_debug_set_wino_min_tiles(1 if request.param == "winograd" else 1 << 30)
+    L.ssie_debug_set_wgrad_wino_min_tiles(1 if request.param == "winograd" else 1 << 30)   # weight gradients: F(3x3,2x2)
     if request.param not in ("heuristic", "winograd"):
         L.ssie_debug_set_fprop_min_tiles16(0)
         L.ssie_debug_set_fprop_wide_min_tiles(1 if request.param == "tile16x32" else 1 << 30)
         L.ssie_debug_set_fprop_v2_split_min_tiles(1 if request.param == "tile16x32" else 1 << 30)   # 32-channel layers: two 4-wave workgroups per CU
     yield request.param
     L.ssie_debug_set_wino_min_tiles(256)
+    L.ssie_debug_set_wgrad_wino_min_tiles(256)
     L.ssie_debug_set_fprop_min_tiles16(256)
     L.ssie_debug_set_fprop_wide_min_tiles(512)
     L.ssie_debug_set_fprop_v2_split_min_tiles(1024)
@@ -148,6 +150,9 @@ def _conv_grads(x, wt, stride, g, transposed=False):
     (64, 1, 3, 1, 16, 16),
     (192, 64, 1, 1, 8, 16),
     (5, 32, 3, 1, 16, 16),
+    (128, 128, 3, 1, 16, 16),
+    (31, 32, 3, 1, 18, 22),
+    (32, 64, 3, 1, 25, 13),
 ])
 def test_conv2d_dgrad_wgrad(H, cin, cout, k, stride, h, w):
     n = 2
