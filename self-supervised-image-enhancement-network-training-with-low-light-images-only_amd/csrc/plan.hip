@@ -783,7 +783,7 @@ int run_ops_overlapped(Plan& pl, std::vector<Fn>& ops, hipStream_t st)
     bool pending[2] = {false, false};
     int rc = 0;
     for (auto& f : ops) {
-        if (f.kind == K_WGRAD) {
+        if (f.kind == K_WGRAD || f.kind == K_WGRAD_WINO) {
             if (pending[f.slab]) { hipStreamWaitEvent(st, pl.ev_r[f.slab], 0); pending[f.slab] = false; }
             if (f(st)) { rc = SSIE_E_LAUNCH; break; }
             hipEventRecord(pl.ev_w[f.slab], st);
