@@ -157,7 +157,8 @@ def run_train(args, torch, dist, hostlib, model, world, rank, dev):
         # the EXECUTED FLOPs, the direct-convolution figure is reported beside it
         executed = WINO_EXECUTED if "winograd" in dom else 1.0
         ach = fl * executed / (ms * 1e-3) / 1e12
-        sub = ("conv_wgrad_kernel" if "wgrad" in dom else "conv_wino_kernel" if "winograd" in dom
+        sub = ("conv_wgrad_kernel" if "wgrad" in dom else "conv_wgrad_wino_kernel" if "winograd" in dom and "weight" in dom
+               else "conv_wino_kernel" if "winograd" in dom
                else "conv_fprop_v2w_kernel" if bands <= 64 else "conv_fprop_v2")
         traffic, tk, tsrc = dominant_traffic(sub, args.workload)
         out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",

@@ -1,0 +1,15 @@
+#!/bin/bash
+# dev tool (GPU box): SQ counters of every kernel of the train step, summarised per kernel.  usage: bash tools/pmc_step.sh [filter]
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/pmc_step
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; }
+done
+python3 $R/tools/pmc_summary.py $OUT/p1 $OUT/p2 $OUT/p3 --filter "${1:-wino}" > $OUT/summary.txt
+find $OUT -name "*.csv" -delete; find $OUT -name "*.db" -delete
+cat $OUT/summary.txt
