@@ -22,6 +22,25 @@
 
 __device__ f32x4 wino_zero_page[4];   // zero-initialised: source of padding slots
 
+// Diagnostic build only (-DSSIE_STAMP, tools/stamp_wino.py): wave 0's s_memtime per phase, summed per workgroup:
+// [0] start [1] wait for the step's DMA (vmcnt) [2] wait at the barrier [3] end [5] epilogue + tile bookkeeping [6] tiles
+// [7] the step bodies.  The shipped library never executes a stamp.
+#ifdef SSIE_STAMP
+__device__ unsigned long long* ssie_stamp_buf_wino = nullptr;
+extern "C" int ssie_debug_set_stamp_buffer_wino(void* buf)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(ssie_stamp_buf_wino), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+#define ST_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t_ = __builtin_amdgcn_s_memtime(); st_[0] = st_t_;
+#define ST_ACC(k) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_[k] += t_ - st_t_; st_t_ = t_; } while (0)
+#define ST_FLUSH do { st_[3] = __builtin_amdgcn_s_memtime(); if (ssie_stamp_buf_wino && threadIdx.x == 0) \
+    for (int k_ = 0; k_ < 8; ++k_) ssie_stamp_buf_wino[(size_t)blockIdx.x * 8 + k_] = st_[k_]; } while (0)
+#else
+#define ST_DECL
+#define ST_ACC(k)
+#define ST_FLUSH
+#endif
+
 #define GLDS16(gptr, lptr)                                                                             \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),            \
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
@@ -213,8 +232,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const unsigned xlo_ = max(0, -vx0_), xn_ = min(W_HPW, p.Wv - vx0_) - xlo_;                        \
             const int jn_ = (s_.C - c0_ + 3) >> 2;                                                            \
             const unsigned long long zp_ = (unsigned long long)wino_zero_page;                                \
+            /* all table entries first: a DMA writes LDS, so the compiler will not move a table read above the previous DMA */ \
+            unsigned te_[W_HPB / NTHR];                                                                       \
+            _Pragma("unroll") for (int i_ = 0; i_ < W_HPB / NTHR; ++i_) te_[i_] = (unsigned)dma_tab[i_ * NTHR + tid]; \
             _Pragma("unroll") for (int i_ = 0; i_ < W_HPB / NTHR; ++i_) {                                     \
-                const unsigned e_ = (unsigned)dma_tab[i_ * NTHR + tid];                                       \
+                const unsigned e_ = te_[i_];                                                                  \
                 const unsigned hy_ = (e_ >> 17) & 31, hx_ = e_ >> 22, j_ = (e_ >> 15) & 3;                    \
                 const bool ok_ = hy_ - ylo_ < yn_ && hx_ - xlo_ < xn_ && (int)j_ < jn_;                       \
                 const int off_ = tb_ + (int)(e_ & 0x7fff) * s_.cstride + 4 * (int)j_;                         \
@@ -231,6 +253,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int gstep = 0;
     WN_PREFETCH(0, n, a0, b0, co0, 0)
     int fetched = 0x7fffffff;
+    ST_DECL
 
     while (tile < total_tiles) {
         f32x4 acc[16][2];
@@ -251,8 +274,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     if (step == 0) *s_next = p.tile_counter ? (int)gridDim.x + atomicAdd(p.tile_counter, 1) : tile + (int)gridDim.x;
                 } else if (step == 1) *s_next = fetched;
             }
+            ST_ACC(5);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ST_ACC(1);
             __syncthreads();
+            ST_ACC(2);
             if (step == (nsteps > 1 ? 1 : 0)) {
                 ntile = *s_next;
                 if (ntile < total_tiles) WN_DECODE(ntile, nn, na0, nb0, nco0)
@@ -269,6 +295,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const f32x4 t = *(const f32x4*)(Ab + ((a * (W_HPW / 2) + (b >> 1)) + (b & 1) * W_HALF) * 16);
                     d[a][b][0] = f32x2{t.x, t.y}; d[a][b][1] = f32x2{t.z, t.w};
                 }
+            // U fragments are fetched one transform position ahead of the MFMAs that use them
+            f32x4 bfn0 = Bl[0], bfn1 = Bl[16];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 f32x2 r[4][2], v[4][2];
@@ -287,7 +315,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int xi = i * 4 + j;
-                    const f32x4 bf0 = Bl[(xi * 4) * 32], bf1 = Bl[(xi * 4) * 32 + 16];
+                    const f32x4 bf0 = bfn0, bf1 = bfn1;
+                    if (xi < 15) { bfn0 = Bl[((xi + 1) * 4) * 32]; bfn1 = Bl[((xi + 1) * 4) * 32 + 16]; }
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         acc[xi][0] = MFMA16(v[j][c >> 1][c & 1], bf0[c], acc[xi][0]);
@@ -304,6 +333,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             if (tid == 0 && step == 0 && nsteps > 1 && p.tile_counter)
                 fetched = (int)gridDim.x + atomicAdd(p.tile_counter, 1);
+            ST_ACC(7);
         }
 
         // output transform (lane-local) + epilogue: one pass of 16 outputs per 16-channel half
@@ -333,7 +363,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         n = nn; a0 = na0; b0 = nb0; co0 = nco0; tile = ntile;
+#ifdef SSIE_STAMP
+        st_[6] += 1;
+#endif
     }
+    ST_ACC(5);
+    ST_FLUSH;
 #undef WN_PREFETCH
 #undef WN_DECODE
 }
