@@ -73,7 +73,7 @@ constexpr int RS = T + 1;                          // padded row stride of the r
 // grid (Cp / 8, tiles of this tensor); window origin = (V*a + org, V*b + org); `valid` = 32 for halo windows (org = -4),
 // 24 for the zero-padded gradient tiles of the weight gradient (org = 0)
 __global__ __launch_bounds__(256) void spec_fft_tiles_kernel(const float* __restrict__ in, int cs, int H, int W, int tiles_y, int tiles_x,
-                                                             int org, int valid, float2* __restrict__ out, int m0, int Mtot, int Cp)
+                                                             int org, int valid, float2* __restrict__ out, int m0, int Mtot, int Cp, int ntiles, int ncg)
 {
     // the real tile R and the half-complex tile Cx share one buffer (static LDS is limited to 64 KB): a row is pulled into
     // registers, and only after a barrier written back as its spectrum
@@ -81,8 +81,11 @@ __global__ __launch_bounds__(256) void spec_fft_tiles_kernel(const float* __rest
     float* R = (float*)buf;                        // [CG][T][RS] floats  (33.8 KB of the 34.8 KB)
     float2* Cx = buf;                              // [CG][T][KX] complex
     static_assert(CG * T * RS * 4 <= CG * T * KX * 8, "R must fit inside Cx");
-    // channel group = blockIdx.x (fastest): the groups of one tile run side by side and share the tile's cache lines
-    const int tid = threadIdx.x, mloc = blockIdx.y, c0 = blockIdx.x * CG;
+    // workgroup id -> (tile, channel group), XCD-aware: consecutive ids go round-robin over the 8 XCDs (each with its own L2), so
+    // the channel groups of ONE tile - which share its 128-byte cache lines - take ids 8 apart: same XCD, back to back in time
+    const int tid = threadIdx.x;
+    const int mloc = (blockIdx.x / (8 * ncg)) * 8 + (blockIdx.x & 7), c0 = ((blockIdx.x >> 3) % ncg) * CG;
+    if (mloc >= ntiles) return;
     const int b = mloc % tiles_x, a = (mloc / tiles_x) % tiles_y, n = mloc / (tiles_x * tiles_y);
     const int oy = V * a + org, ox = V * b + org;
     for (int idx = tid; idx < T * T * (CG / 4); idx += 256) {
@@ -126,12 +129,14 @@ __global__ __launch_bounds__(256) void spec_fft_tiles_kernel(const float* __rest
 // ---- Y^ -> y ------------------------------------------------------------------------------------------------------------
 // grid (ceil(cs / 8), tiles); writes the 24 x 24 valid block of tile m: out = (accumulate ? out : 0) + y + bias
 __global__ __launch_bounds__(256) void spec_ifft_out_kernel(const float2* __restrict__ Yf, int m0, int Mtot, int Np, int H, int W, int tiles_y, int tiles_x,
-                                                            float* __restrict__ out, int cs, int Cout, const float* __restrict__ bias, int accumulate)
+                                                            float* __restrict__ out, int cs, int Cout, const float* __restrict__ bias, int accumulate, int ntiles, int ncg)
 {
     __shared__ float2 buf[CG * T * KX];            // Cx, then (after a barrier) the real tile R: see spec_fft_tiles_kernel
     float* R = (float*)buf;
     float2* Cx = buf;
-    const int tid = threadIdx.x, mloc = blockIdx.y, c0 = blockIdx.x * CG;
+    const int tid = threadIdx.x;           // (tile, channel group) from the workgroup id as in spec_fft_tiles_kernel
+    const int mloc = (blockIdx.x / (8 * ncg)) * 8 + (blockIdx.x & 7), c0 = ((blockIdx.x >> 3) % ncg) * CG;
+    if (mloc >= ntiles) return;
     const int b = mloc % tiles_x, a = (mloc / tiles_x) % tiles_y, n = mloc / (tiles_x * tiles_y);
     const size_t m = (size_t)m0 + mloc;
     for (int idx = tid; idx < NF * CG; idx += 256) {
@@ -402,7 +407,8 @@ int ssie_launch_spec_fft(const float* in, int cs, int Cp, int N, int H, int W, i
 {
     int ty, tx; const int per = ssie_spec_tiles(H, W, &ty, &tx);
     if (Cp % CG || cs % 4) return 91;
-    hipLaunchKernelGGL(spec_fft_tiles_kernel, dim3(Cp / CG, N * per), dim3(256), 0, st, in, cs, H, W, ty, tx, halo ? -4 : 0, halo ? T : V, out, m0, Mtot, Cp);
+    const int ntiles = N * per, ncg = Cp / CG;
+    hipLaunchKernelGGL(spec_fft_tiles_kernel, dim3((unsigned)((ntiles + 7) / 8 * 8 * ncg)), dim3(256), 0, st, in, cs, H, W, ty, tx, halo ? -4 : 0, halo ? T : V, out, m0, Mtot, Cp, ntiles, ncg);
     return hipGetLastError() == hipSuccess ? 0 : 92;
 }
 
@@ -411,7 +417,8 @@ int ssie_launch_spec_ifft(const float2* Yf, int m0, int Mtot, int Np, int N, int
 {
     int ty, tx; const int per = ssie_spec_tiles(H, W, &ty, &tx);
     if (cs % 4) return 93;
-    hipLaunchKernelGGL(spec_ifft_out_kernel, dim3((cs + CG - 1) / CG, N * per), dim3(256), 0, st, Yf, m0, Mtot, Np, H, W, ty, tx, out, cs, Cout, bias, accumulate);
+    const int ntiles = N * per, ncg = (cs + CG - 1) / CG;
+    hipLaunchKernelGGL(spec_ifft_out_kernel, dim3((unsigned)((ntiles + 7) / 8 * 8 * ncg)), dim3(256), 0, st, Yf, m0, Mtot, Np, H, W, ty, tx, out, cs, Cout, bias, accumulate, ntiles, ncg);
     return hipGetLastError() == hipSuccess ? 0 : 94;
 }
 
