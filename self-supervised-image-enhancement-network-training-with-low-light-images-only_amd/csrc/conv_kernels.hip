@@ -812,6 +812,7 @@ static int ssie_launch_fprop_nt1(const ConvParams& p, hipStream_t st)
 int ssie_launch_fprop(const ConvParams& p, hipStream_t st)
 {
     if (p.wino) return ssie_launch_fprop_wino(p, st);
+    if (p.tconv) return ssie_launch_tconv(p, st);
     if (ssie_fprop_use_v2 && ssie_fprop_v2_ok(p)) return ssie_launch_fprop_v2(p, st);
     int nt = (p.Cout_pad % 64 == 0) ? 2 : 1;
     if (nt == 2 && (long)p.N * p.tiles_y * p.tiles_x * p.co_blocks < 256) {

@@ -12,6 +12,9 @@ struct Epilogue {
 TapList ssie_taps_conv(int k);
 TapList ssie_taps_dgrad_s1(int k);
 TapList ssie_taps_transposed(int k, int pad, int py, int px);
+TapList ssie_taps_transposed_all(void);          // the nine taps of the 3 x 3 stride-2 case in output-parity class order (1 + 2 + 2 + 4)
+bool ssie_tconv_eligible(const SrcDesc& in, int N, int Hin, int Win, int Nc);
+void ssie_conv_to_tconv(ConvParams& p);
 SrcDesc ssie_make_src(const float* ptr, int C, int cstride, int coff, int Hs, int Ws, int Hv, int Wv);
 size_t ssie_packed_floats(int K, int N, int T);
 PackDesc ssie_make_pack(const float* w, float* dst, int K, int N, const TapList& t, int s_k, int s_n, int s_t);

@@ -48,6 +48,35 @@ TapList ssie_taps_transposed(int k, int pad, int py, int px)
     return t;
 }
 
+TapList ssie_taps_transposed_all(void)
+{
+    TapList t; t.n = 0;
+    for (int py = 0; py < 2; ++py) for (int px = 0; px < 2; ++px) {
+        const TapList c = ssie_taps_transposed(3, 1, py, px);
+        for (int i = 0; i < c.n; ++i) { t.dy[t.n] = c.dy[i]; t.dx[t.n] = c.dx[i]; t.sel[t.n] = c.sel[i]; ++t.n; }
+    }
+    return t;
+}
+
+// ---- one-launch transposed convolution (conv_tconv.hip) ----
+int ssie_fprop_tconv = 1;              // A/B switch: 1 = eligible stride-2 transposed 3x3 convolutions run conv_tconv_kernel
+int ssie_fprop_tconv_min_tiles = 256;  // ... when the input has at least this many 16 x 16 tiles (tests set 1)
+extern "C" void ssie_debug_set_tconv(int v) { ssie_fprop_tconv = v; }
+extern "C" void ssie_debug_set_tconv_min_tiles(int v) { ssie_fprop_tconv_min_tiles = v; }
+
+bool ssie_tconv_eligible(const SrcDesc& in, int N, int Hin, int Win, int Nc)
+{
+    if (!ssie_fprop_tconv || Nc <= 32 || Nc > 64 || in.sy != 1.f || in.sx != 1.f || in.Hs != Hin || in.Ws != Win || Hin < 16 || Win < 16) return false;
+    return (long)N * ssie_ceil_div(Hin, 16) * ssie_ceil_div(Win, 16) >= ssie_fprop_tconv_min_tiles;
+}
+
+// re-target a geometry built over ssie_taps_transposed_all (si = 1, so = 2, Ho x Wo = the INPUT grid) at conv_tconv_kernel
+void ssie_conv_to_tconv(ConvParams& p)
+{
+    p.tconv = 1; p.th = 16; p.tw = 16; p.hp_h = 17; p.hp_w = 17;
+    p.tiles_y = ssie_ceil_div(p.Ho, 16); p.tiles_x = ssie_ceil_div(p.Wo, 16); p.co_blocks = 1;
+}
+
 static void tap_extent(const TapList& t, int& mn_y, int& mx_y, int& mn_x, int& mx_x)
 {
     mn_y = mn_x = 127; mx_y = mx_x = -127;
@@ -341,6 +370,20 @@ static int transposed_like(const SrcDesc& in, int N, int Hin, int Win, int Kc, i
 {
     int* counters = take_counters(cur, end, 4, st);
     if (!counters) return SSIE_E_WORKSPACE;
+    if (ssie_tconv_eligible(in, N, Hin, Win, Nc)) {
+        // all four output-parity classes in one launch
+        TapList t = ssie_taps_transposed_all();
+        float* wp = ws_take(cur, end, ssie_packed_floats(Kc, Nc, t.n));
+        if (!wp) return SSIE_E_WORKSPACE;
+        PackDesc pd = ssie_make_pack(weight, wp, Kc, Nc, t, s_k, s_n, 1);
+        if (ssie_launch_pack(pd, st)) return SSIE_E_LAUNCH;
+        ConvParams p;
+        int rc = ssie_make_conv(p, &in, 1, N, Hin, Win, t, 1, Hin, Win, wp, Nc, out, Hout, Wout, out_cstride, out_coff, 2, 0, 0, e);
+        if (rc) return rc;
+        ssie_conv_to_tconv(p);
+        p.tile_counter = counters;
+        return ssie_launch_fprop(p, st) ? SSIE_E_LAUNCH : 0;
+    }
     for (int py = 0; py < 2; ++py) for (int px = 0; px < 2; ++px) {
         TapList t = ssie_taps_transposed(3, 1, py, px);
         float* wp = ws_take(cur, end, ssie_packed_floats(Kc, Nc, t.n));

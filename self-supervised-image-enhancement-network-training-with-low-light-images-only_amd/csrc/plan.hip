@@ -235,7 +235,7 @@ struct Builder {
         // algorithmic FLOPs: real (un-padded) channels and taps only
         const double fl = 2.0 * p.N * p.Ho * p.Wo * (double)p.Cout * k_real * p.ntaps;
         char tag[96];
-        snprintf(tag, sizeof(tag), "%sconv k%d->n%d taps%d si%d so%d %dx%d", p.wino ? "winograd " : "", k_real, p.Cout, p.ntaps, p.si, p.so, p.Ho, p.Wo);
+        snprintf(tag, sizeof(tag), "%sconv k%d->n%d taps%d si%d so%d %dx%d", p.wino ? "winograd " : p.tconv ? "transposed (4 classes) " : "", k_real, p.Cout, p.ntaps, p.si, p.so, p.Ho, p.Wo);
         if (h16) {
             std::string t16 = std::string("bf16 ") + tag;
             ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_fprop_bf16(p, st); }, p.Cout_pad % 64 == 0 ? K_FPROP2 : K_FPROP1, fl, t16));
@@ -287,10 +287,23 @@ struct Builder {
                    const char* out, const Epilogue& e)
     {
         const BufInfo& ob = pl.bi(out);
+        // all four output-parity classes in one launch where the input fills the chip (conv_tconv.hip); the pack is reserved
+        // either way so that the dry run and the real build walk the same cursor
+        float* wpm = take_pack(ssie_packed_floats(Kc, Nc, 9));
+        const bool merged = !dry && !h16 && ssie_tconv_eligible(in, pl.N, Hin, Win, Nc) && ob.H <= 2 * Hin && ob.W <= 2 * Win;
+        if (merged) {
+            TapList t = ssie_taps_transposed_all();
+            pl.packs.push_back(ssie_make_pack(wbase, wpm, Kc, Nc, t, s_k, s_n, 1));
+            ConvParams p;
+            int rc = ssie_make_conv(p, &in, 1, pl.N, Hin, Win, t, 1, Hin, Win, wpm, Nc, pl.buf(out), ob.H, ob.W, ob.cs, 0, 2, 0, 0, e);
+            if (rc) return rc;
+            ssie_conv_to_tconv(p);
+            push(ops, p, Kc);
+        }
         for (int py = 0; py < 2; ++py) for (int px = 0; px < 2; ++px) {
             TapList t = ssie_taps_transposed(3, 1, py, px);
             float* wp = take_pack(ssie_packed_floats(Kc, Nc, t.n));
-            if (dry) continue;
+            if (dry || merged) continue;
             ConvParams p;
             const int Ho = ssie_ceil_div(ob.H - py, 2), Wo = ssie_ceil_div(ob.W - px, 2);
             if (h16) {

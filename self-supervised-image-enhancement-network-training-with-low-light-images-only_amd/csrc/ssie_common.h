@@ -75,6 +75,7 @@ struct ConvParams {
     int* tile_counter;      // optional dynamic tile queue (device int, zero before the launch); null = static stride
     int out_bf16;           // bf16 inference kernel only: element type of `out` (addsrc / out2 are always bf16 there)
     int wino;               // 1: geometry and weights (U = G g G^T, 16 transform positions) of conv_wino_kernel (conv_wino.hip)
+    int tconv;              // 1: all four output-parity classes of a stride-2 transposed 3 x 3 convolution in one launch (conv_tconv.hip)
 };
 
 struct WgradParams {
@@ -111,6 +112,7 @@ struct PackDesc {
 int ssie_launch_fprop(const ConvParams& p, hipStream_t st);
 bool ssie_fprop_v2_ok(const ConvParams& p);            // conv_fprop_v2.hip
 int ssie_launch_fprop_v2(const ConvParams& p, hipStream_t st);
+int ssie_launch_tconv(const ConvParams& p, hipStream_t st);        // conv_tconv.hip; p over ssie_taps_transposed_all
 int ssie_launch_fprop_wino(const ConvParams& p, hipStream_t st);   // conv_wino.hip; p from ssie_conv_to_wino
 int ssie_launch_fprop_bf16(const ConvParams& p, hipStream_t st);   // conv_fprop_bf16.hip; p from ssie_make_conv_bf16
 extern int ssie_fprop_min_tiles16;                     // launches with fewer tiles than this use the 8 x 16 register-staged kernel (layer_ops.hip)

@@ -20,21 +20,24 @@ def H():
     return hostlib
 
 
-@pytest.fixture(autouse=True, params=["heuristic", "tile16x16", "tile16x32", "winograd"])
+@pytest.fixture(autouse=True, params=["heuristic", "tile16x16", "tile16x32", "winograd", "tconv1"])
 def kernel_mode(H, request):
     """The launch heuristics pick 8x16 tiles (register-staged kernel) for launches as small as these tests; the two forced
     modes run the same cases through the DMA kernels the bench-size layers use: 16x16 tiles (conv_fprop_v2_kernel) and
     16x32 tiles (conv_fprop_v2w_kernel, where eligible: stride 1, <= 9 taps, 64-multiple Cout, Wo >= 32).  "winograd" runs
     every stride-1 3x3 forward / data-gradient launch on conv_wino_kernel (F(2x2, 3x3), conv_wino.hip), whatever its size;
-    the other three modes keep it off so the direct kernels stay covered."""
+    the other three modes keep it off so the direct kernels stay covered.  "tconv1" runs every eligible stride-2 transposed 3x3
+    convolution (ConvTranspose2d forward, stride-2 data gradient) on the one-launch kernel (conv_tconv.hip) whatever its size."""
     L = H.lib()
     L.ssie_debug_set_wino_min_tiles(1 if request.param == "winograd" else 1 << 30)
+    L.ssie_debug_set_tconv_min_tiles(1 if request.param == "tconv1" else 1 << 30)
     L.ssie_debug_set_wgrad_wino_min_tiles(1 if request.param == "winograd" else 1 << 30)   # weight gradients: F(3x3,2x2)
     if request.param not in ("heuristic", "winograd"):
         L.ssie_debug_set_fprop_min_tiles16(0)
         L.ssie_debug_set_fprop_wide_min_tiles(1 if request.param == "tile16x32" else 1 << 30)
         L.ssie_debug_set_fprop_v2_split_min_tiles(1 if request.param == "tile16x32" else 1 << 30)   # 32-channel layers: two 4-wave workgroups per CU
     yield request.param
+    L.ssie_debug_set_tconv_min_tiles(256)
     L.ssie_debug_set_wino_min_tiles(256)
     L.ssie_debug_set_wgrad_wino_min_tiles(256)
     L.ssie_debug_set_fprop_min_tiles16(256)
