@@ -35,7 +35,8 @@ constexpr int GW_TH = 8, GW_TW = 16, GW_HPH = 10, GW_HPW = 18;     // position t
 constexpr int GW_NT = (GW_TH / 2) * (GW_TW / 2);                    // 32 Winograd tiles per position tile
 }
 
-template <int CIB, int COB>
+// UP: the source is nearest-up-sampled on read (F.interpolate(mode='nearest'), model.py:156-169), resolved per staged slot
+template <int CIB, int COB, bool UP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wgrad_wino_kernel(const WgradParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -85,7 +86,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const unsigned pix_ = (unsigned)id_ / CI4, j_ = (unsigned)id_ % CI4;                              \
             const unsigned hy_ = (pix_ * 3641u) >> 16, hx_ = pix_ - hy_ * GW_HPW;   /* / 18 for pix < 4000 */   \
             const bool ok_ = hy_ - ylo_ < yn_ && hx_ - xlo_ < xn_ && (int)j_ < jn_ && id_ < GW_HPH * GW_HPW * CI4; \
-            const int off_ = tbx_ + (int)(hy_ * p.Wv + hx_) * p.src.cstride + 4 * (int)j_;                    \
+            int off_ = tbx_ + (int)(hy_ * p.Wv + hx_) * p.src.cstride + 4 * (int)j_;                          \
+            if (UP) {                                                                                         \
+                const int cy_ = min(max(a0_ - 1 + (int)hy_, 0), p.Hv - 1), cx_ = min(max(b0_ - 1 + (int)hx_, 0), p.Wv - 1); \
+                const int sy_ = min((int)floorf((float)cy_ * p.src.sy), p.src.Hs - 1), sx_ = min((int)floorf((float)cx_ * p.src.sx), p.src.Ws - 1); \
+                off_ = ((n_ * p.src.Hs + sy_) * p.src.Ws + sx_) * p.src.cstride + p.src.coff + ci0 + 4 * (int)j_; \
+            }                                                                                                 \
             const unsigned long long a_ = (unsigned long long)(p.src.ptr + off_), m_ = ok_ ? ~0ull : 0ull;    \
             if (NX * 256 == GW_HPH * GW_HPW * CI4 || id_ < GW_HPH * GW_HPW * CI4)                             \
                 GLDS16G((const f32x4*)((a_ & m_) | (zp_ & ~m_)), (f32x4*)(Xs0 + (BUF) * XSZ) + it_ * 256 + wave * 64); \
@@ -212,10 +218,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
-template __global__ void conv_wgrad_wino_kernel<64, 64>(const WgradParams);
-template __global__ void conv_wgrad_wino_kernel<32, 64>(const WgradParams);
-template __global__ void conv_wgrad_wino_kernel<64, 32>(const WgradParams);
-template __global__ void conv_wgrad_wino_kernel<32, 32>(const WgradParams);
+template __global__ void conv_wgrad_wino_kernel<64, 64, false>(const WgradParams);
+template __global__ void conv_wgrad_wino_kernel<32, 64, false>(const WgradParams);
+template __global__ void conv_wgrad_wino_kernel<64, 32, false>(const WgradParams);
+template __global__ void conv_wgrad_wino_kernel<32, 32, false>(const WgradParams);
+template __global__ void conv_wgrad_wino_kernel<64, 64, true>(const WgradParams);
 
 // dU[xi][ci][co] (summed over the slices by wgrad_reduce_kernel) -> dW[co][ci][3 x 3]: scale by the 1/2 factors left out of H, then
 // A^T (.) A with A^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,1]]
@@ -260,17 +267,19 @@ int ssie_launch_wgrad_wino(const WgradParams& p, hipStream_t st)
     const int cib = p.ci_pad / p.ci_blocks, cob = p.co_pad / p.co_blocks;
     if (p.ntaps != 9 || p.si != 1 || p.th != GW_TH || p.hp_h != GW_HPH || p.hp_w != GW_HPW || p.min_dy != -1 || p.min_dx != -1) return 41;
     for (int t = 0; t < 9; ++t) if (p.tap_dy[t] != t / 3 - 1 || p.tap_dx[t] != t % 3 - 1) return 42;
-    if (p.src.sy != 1.f || p.src.sx != 1.f || p.src.Hs != p.Hv || p.src.Ws != p.Wv) return 43;
+    const bool up = p.src.sy != 1.f || p.src.sx != 1.f || p.src.Hs != p.Hv || p.src.Ws != p.Wv;
+    if (up && !(cib == 64 && cob == 64)) return 43;              // the up-sampled sources of this network are 64 -> 64 layers
     const size_t lds = ssie_wgrad_wino_lds_bytes(cib, cob);
     dim3 grid(p.nslices, p.ci_blocks * p.co_blocks, 1);
-    static unsigned seen[4] = {0, 0, 0, 0};
-#define GW_LAUNCH(CI, CO, K)                                                                                  \
-    { ssie_allow_full_lds((const void*)conv_wgrad_wino_kernel<CI, CO>, seen[K]);                              \
-      hipLaunchKernelGGL((conv_wgrad_wino_kernel<CI, CO>), grid, dim3(256), lds, st, p); }
-    if (cib == 64 && cob == 64) GW_LAUNCH(64, 64, 0)
-    else if (cib == 32 && cob == 64) GW_LAUNCH(32, 64, 1)
-    else if (cib == 64 && cob == 32) GW_LAUNCH(64, 32, 2)
-    else if (cib == 32 && cob == 32) GW_LAUNCH(32, 32, 3)
+    static unsigned seen[5] = {0, 0, 0, 0, 0};
+#define GW_LAUNCH(CI, CO, U, K)                                                                               \
+    { ssie_allow_full_lds((const void*)conv_wgrad_wino_kernel<CI, CO, U>, seen[K]);                           \
+      hipLaunchKernelGGL((conv_wgrad_wino_kernel<CI, CO, U>), grid, dim3(256), lds, st, p); }
+    if (up) GW_LAUNCH(64, 64, true, 4)
+    else if (cib == 64 && cob == 64) GW_LAUNCH(64, 64, false, 0)
+    else if (cib == 32 && cob == 64) GW_LAUNCH(32, 64, false, 1)
+    else if (cib == 64 && cob == 32) GW_LAUNCH(64, 32, false, 2)
+    else if (cib == 32 && cob == 32) GW_LAUNCH(32, 32, false, 3)
     else return 44;
 #undef GW_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : 45;

@@ -275,10 +275,11 @@ int ssie_make_wgrad(WgradParams& p, const SrcDesc& src, int N, int Hv, int Wv, i
     if (p.rows2) p.tap_groups = ssie_ceil_div(p.tap_groups, 2);
     p.tiles_y = ssie_ceil_div(Ho, p.th); p.tiles_x = ssie_ceil_div(Wo, SSIE_TW);
     p.tiles_total = N * p.tiles_y * p.tiles_x;
-    // Winograd F(3x3,2x2): full 3 x 3 in forward tap order, stride 1, same-size output, source read 1:1; one workgroup per CU
+    // Winograd F(3x3,2x2): full 3 x 3 in forward tap order, stride 1, same-size output (an up-sampled source: 64 x 64 blocks only); one workgroup per CU
     // (256 accumulator registers per wave), so half the slices of the direct kernel
-    p.wino = ssie_wgrad_wino && taps_are_3x3(t) && si == 1 && Ho == Hv && Wo == Wv && src.sy == 1.f && src.sx == 1.f &&
-             src.Hs == Hv && src.Ws == Wv && p.tiles_total >= ssie_wgrad_wino_min_tiles;
+    const bool up = src.sy != 1.f || src.sx != 1.f || src.Hs != Hv || src.Ws != Wv;
+    p.wino = ssie_wgrad_wino && taps_are_3x3(t) && si == 1 && Ho == Hv && Wo == Wv && (!up || (cib == 64 && cob == 64)) &&
+             p.tiles_total >= ssie_wgrad_wino_min_tiles;
     for (int i = 0; p.wino && i < 9; ++i) if (t.dy[i] != i / 3 - 1 || t.dx[i] != i % 3 - 1) p.wino = 0;
     if (p.wino) { p.tap_groups = 1; p.rows2 = 0; target_wgs = (target_wgs + 1) / 2; }
     int per = p.ci_blocks * p.co_blocks * p.tap_groups;
