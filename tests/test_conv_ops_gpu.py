@@ -81,6 +81,8 @@ def close(got, ref, tol=TOL):
     (64, 64, 3, 1, 32, 64, 1),
     (96, 64, 3, 1, 20, 40, 0),
     (128, 128, 3, 1, 16, 48, 1),
+    (48, 96, 3, 1, 33, 47, 1),          # three K chunks, 96 -> padded 128 output channels, odd ragged sizes
+    (128, 31, 3, 1, 17, 40, 0),
 ])
 def test_conv2d_fwd(H, cin, cout, k, stride, h, w, act):
     n = 2
@@ -156,6 +158,8 @@ def _conv_grads(x, wt, stride, g, transposed=False):
     (128, 128, 3, 1, 16, 16),
     (31, 32, 3, 1, 18, 22),
     (32, 64, 3, 1, 25, 13),
+    (48, 96, 3, 1, 33, 47),
+    (128, 31, 3, 1, 17, 40),
 ])
 def test_conv2d_dgrad_wgrad(H, cin, cout, k, stride, h, w):
     n = 2
