@@ -169,10 +169,18 @@ def forced_kernels(pkg, request):
 
 @pytest.mark.parametrize("case", list(CASES))
 def test_backward_chain_injected(pkg, case, forced_kernels):
-    if forced_kernels and case in ("b5_16", "b256_64", "b5_256"):
-        pytest.skip("forced-kernel variant runs on the mid-size cases only (time)")
+    if forced_kernels and (case in ("b5_16", "b5_256") or (case == "b256_64" and forced_kernels != "winograd")):
+        pytest.skip("forced-kernel variant runs on the mid-size cases only (time); 256 bands: the Winograd / tconv kernels only")
     n, bands, h, w, coefs = CASES[case]
     check_chain(pkg, case, n, bands, h, w, coefs, forced_kernels)
+
+
+def test_backward_chain_256_bands_bench_kernels(pkg):
+    """BASELINE configs[2] (128 x 128 x 256) with the REAL launch heuristics at a batch that keeps >= 256 tiles per layer
+    (N = 8: 512 16x32 tiles at full resolution), i.e. the kernels the N = 32 plan selects: conv_wino / conv_wgrad_wino with
+    256 -> 32, 64 -> 257 (ragged last output-channel block) and 257 -> 64 operands, the one-launch transposed convolution and
+    the frequency-domain 9 x 9 at 256 input channels.  Same fixed 2e-5 as every other chain case (model.py:315)."""
+    check_chain(pkg, "b256_128_n8", 8, 256, 128, 128, O.JYU_COEFS)
 
 
 ONE_HOT = ["c_rec", "c_rf", "c_il", "c_id", "c_f", "c_sp"]

@@ -83,6 +83,10 @@ def close(got, ref, tol=TOL):
     (128, 128, 3, 1, 16, 48, 1),
     (48, 96, 3, 1, 33, 47, 1),          # three K chunks, 96 -> padded 128 output channels, odd ragged sizes
     (128, 31, 3, 1, 17, 40, 0),
+    (256, 32, 3, 1, 16, 32, 1),         # the 256-band layers of BASELINE configs[2]: conv0 (16 K chunks),
+    (64, 257, 3, 1, 16, 32, 2),         # recon (257 = 9 output-channel blocks, ragged last one), sigmoid
+    (257, 64, 3, 1, 16, 32, 1),         # the illumination net's conv0 on cat[R, I]
+    (256, 64, 9, 1, 16, 16, 0),         # shallow_conv (direct 9 x 9 kernels; the spectral path is a plan-level test)
 ])
 def test_conv2d_fwd(H, cin, cout, k, stride, h, w, act):
     n = 2
@@ -160,6 +164,10 @@ def _conv_grads(x, wt, stride, g, transposed=False):
     (32, 64, 3, 1, 25, 13),
     (48, 96, 3, 1, 33, 47),
     (128, 31, 3, 1, 17, 40),
+    (256, 32, 3, 1, 16, 32),
+    (64, 257, 3, 1, 16, 32),
+    (257, 64, 3, 1, 16, 32),
+    (256, 64, 9, 1, 16, 16),
 ])
 def test_conv2d_dgrad_wgrad(H, cin, cout, k, stride, h, w):
     n = 2

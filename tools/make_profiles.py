@@ -16,8 +16,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
+    """kernel name without return type, the '(anonymous namespace)::' qualifier and the trailing ARGUMENT list (template
+    arguments stay, so variants of one kernel keep their own rows)"""
     name = re.sub(r"^void ", "", name)
-    name = re.sub(r"\(.*$", "", name)
+    name = name.replace("(anonymous namespace)::", "")
+    depth = 0
+    for i, ch in enumerate(name):          # the argument list = the first '(' outside template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            name = name[:i]
+            break
     return name.strip()
 
 
