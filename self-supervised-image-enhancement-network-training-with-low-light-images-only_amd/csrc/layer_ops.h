@@ -15,6 +15,7 @@ TapList ssie_taps_transposed(int k, int pad, int py, int px);
 TapList ssie_taps_transposed_all(void);          // the nine taps of the 3 x 3 stride-2 case in output-parity class order (1 + 2 + 2 + 4)
 bool ssie_tconv_eligible(const SrcDesc& in, int N, int Hin, int Win, int Nc);
 void ssie_conv_to_tconv(ConvParams& p);
+bool ssie_fits_i32(long n, long h, long w, long cstride);   // n*h*w*cstride <= 2^31 - 1: the kernels' 32-bit element offsets cannot wrap
 SrcDesc ssie_make_src(const float* ptr, int C, int cstride, int coff, int Hs, int Ws, int Hv, int Wv);
 size_t ssie_packed_floats(int K, int N, int T);
 PackDesc ssie_make_pack(const float* w, float* dst, int K, int N, const TapList& t, int s_k, int s_n, int s_t);

@@ -77,6 +77,15 @@ void ssie_conv_to_tconv(ConvParams& p)
     p.tiles_y = ssie_ceil_div(p.Ho, 16); p.tiles_x = ssie_ceil_div(p.Wo, 16); p.co_blocks = 1;
 }
 
+// The kernels index activations with 32-bit element offsets (conv_wino.hip tb_, conv_wgrad_wino.hip tbx_/tbg_, conv_tconv.hip
+// off_, the DMA slot tables): a tensor of 2^31 or more floats would wrap into wrong addresses, so geometry builders reject it.
+bool ssie_fits_i32(long n, long h, long w, long cstride)
+{
+    if (n < 0 || h < 0 || w < 0 || cstride < 0) return false;
+    const unsigned __int128 e = (unsigned __int128)(unsigned long)n * (unsigned long)h * (unsigned long)w * (unsigned long)cstride;
+    return e <= (unsigned __int128)0x7fffffff;
+}
+
 static void tap_extent(const TapList& t, int& mn_y, int& mx_y, int& mn_x, int& mx_x)
 {
     mn_y = mn_x = 127; mx_y = mx_x = -127;
@@ -124,8 +133,10 @@ int ssie_make_conv(ConvParams& p, const SrcDesc* srcs, int nsrc, int N, int Hv, 
         if (srcs[s].C % 4 || srcs[s].cstride % 4 || srcs[s].coff % 4) return SSIE_E_SHAPE;
         if (nsrc > 1 && srcs[s].C % SSIE_CK) return SSIE_E_SHAPE;
         if (((uintptr_t)srcs[s].ptr) % 16) return SSIE_E_SHAPE;
+        if (!ssie_fits_i32(N, srcs[s].Hs, srcs[s].Ws, srcs[s].cstride)) return SSIE_E_SHAPE;
         cin += srcs[s].C;
     }
+    if (!ssie_fits_i32(N, Hout, Wout, out_cstride)) return SSIE_E_SHAPE;
     // the epilogue moves 16 bytes along the channel axis per access (conv_device.h, ssie_epilogue_t)
     if (out_cstride % 4 || out_coff % 4 || ((uintptr_t)out | (uintptr_t)e.bias | (uintptr_t)e.addsrc | (uintptr_t)e.out2 | (uintptr_t)e.mask_y) % 16)
         return SSIE_E_SHAPE;
@@ -256,6 +267,7 @@ int ssie_make_wgrad(WgradParams& p, const SrcDesc& src, int N, int Hv, int Wv, i
 {
     memset(&p, 0, sizeof(p));
     if (src.C % 4 || src.cstride % 4 || src.coff % 4 || g_cstride % 4 || g_coff % 4) return SSIE_E_SHAPE;
+    if (!ssie_fits_i32(N, src.Hs, src.Ws, src.cstride) || !ssie_fits_i32(N, Ho, Wo, g_cstride)) return SSIE_E_SHAPE;
     p.src = src; p.N = N; p.Hv = Hv; p.Wv = Wv; p.ci0_total = ci0_weight; p.Cin = src.C;
     p.g = g; p.g_cstride = g_cstride; p.g_coff = g_coff; p.Cout = Cout; p.Ho = Ho; p.Wo = Wo; p.si = si;
     p.ntaps = t.n;
@@ -310,7 +322,11 @@ extern "C" size_t ssie_op_workspace_bytes(int cin, int cout, int k)
 {
     const int T = k * k;
     size_t packed = 4 * ssie_packed_floats(cin > cout ? cin : cout, cin > cout ? cin : cout, T);
-    size_t slabs = (size_t)kTargetWgs * (T < SSIE_TG ? T : SSIE_TG) * 64 * 64 + (size_t)T * ssie_round_up(cin, 64) * ssie_round_up(cout, 64);
+    // slabs: the direct kernels write kTargetWgs slices of one tap group; the Winograd weight gradient (3 x 3) writes
+    // kTargetWgs / 2 slices of 16 transform positions (8 per target workgroup < 9).  Behind them: the per-layer remainder and,
+    // for the Winograd path, the dU[16][ci][co] scratch of ssie_run_wgrad
+    const int tg = T < SSIE_TG ? T : SSIE_TG;
+    size_t slabs = (size_t)kTargetWgs * tg * 64 * 64 + (size_t)(T > 16 ? T : 16) * ssie_round_up(cin, 64) * ssie_round_up(cout, 64);
     size_t partial = (size_t)256 * ssie_round_up(cout > cin ? cout : cin, 4);
     return (packed + slabs * 2 + partial) * sizeof(float) + 4096;
 }
@@ -480,13 +496,12 @@ int ssie_run_wgrad(const SrcDesc& x, int x_creal, int N, int Hv, int Wv, const f
     if (rc) return rc;
     const size_t need = ssie_wgrad_slab_floats(p);
     const size_t bneed = db ? (size_t)p.nslices * p.co_pad : 0;
-    if (need + bneed > slab_cap_floats) return SSIE_E_WORKSPACE;
+    const size_t du_floats = p.wino ? (size_t)16 * x_creal * gC : 0;     // Winograd: dU[16][ci][co] behind the slabs
+    if (need + bneed + du_floats > slab_cap_floats) return SSIE_E_WORKSPACE;   // checked BEFORE anything is enqueued
     p.bias_slabs = db ? slabs + need : nullptr;
     if (ssie_launch_wgrad(p, st)) return SSIE_E_LAUNCH;
     if (p.wino) {
         // slabs -> dU[16][ci][co] (fixed-order sum over the slices) -> the nine taps
-        const size_t du_floats = (size_t)16 * x_creal * gC;
-        if (need + bneed + du_floats > slab_cap_floats) return SSIE_E_WORKSPACE;
         float* du = slabs + need + bneed;
         if (ssie_launch_wgrad_reduce(slabs, p.nslices, 16, p.ci_pad, p.co_pad, x_creal, gC, du, 1, gC, (long)x_creal * gC,
                                      p.bias_slabs, db, 0, st, accumulate)) return SSIE_E_LAUNCH;

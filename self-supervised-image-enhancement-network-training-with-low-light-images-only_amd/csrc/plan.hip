@@ -25,10 +25,16 @@ namespace {
 typedef std::function<int(hipStream_t)> FnT;
 // op kinds for per-kernel-class profiling (bench.py roofline): see ssie_plan_profile_step
 enum { K_FPROP2 = 0, K_FPROP1, K_WGRAD, K_WGRAD_REDUCE, K_COLSUM, K_PACK, K_LOSS, K_FFT, K_ATTN, K_ELEMENTWISE, K_SPEC, K_WINO, K_WGRAD_WINO, K_NKINDS };
+// How a launch touches the two weight-gradient slab areas (run_ops_overlapped orders the streams by THIS, never by kind):
+//   SLAB_WRITE  produces partial slabs in area `slab` on the main stream (any weight-gradient kernel)
+//   SLAB_READ   consumes area `slab` on the side stream (slab reduction, Winograd tap extraction - anything reading the area)
+enum { SLAB_NONE = 0, SLAB_WRITE = 1, SLAB_READ = 2 };
 struct Fn {
     FnT fn; int kind; double flops; std::string tag;
-    int slab = 0;       // K_WGRAD / K_WGRAD_REDUCE: which of the two slab areas the launch writes / reads
-    Fn(FnT f, int k = K_ELEMENTWISE, double fl = 0.0, std::string t = "", int sl = 0) : fn(std::move(f)), kind(k), flops(fl), tag(std::move(t)), slab(sl) {}
+    int slab = 0;       // which of the two slab areas
+    int slab_use = SLAB_NONE;
+    Fn(FnT f, int k = K_ELEMENTWISE, double fl = 0.0, std::string t = "", int sl = 0, int use = SLAB_NONE)
+        : fn(std::move(f)), kind(k), flops(fl), tag(std::move(t)), slab(sl), slab_use(use) {}
     int operator()(hipStream_t st) const { return fn(st); }
 };
 
@@ -165,7 +171,11 @@ void build_buffers(Plan& pl)
     // bf16 inference path: bf16 copies of the tensors that also exist in fp32 (allocated in float units: C/2)
     alloc(pl, "xh", N, H, W, ssie_round_up(B, 8) / 2); alloc(pl, "RLh", N, H, W, ssie_round_up(B + 1, 8) / 2); alloc(pl, "aoh", N, H8, W8, 32);
     // scratch
-    pl.slab_cap = (size_t)kWgs * 9 * 64 * 64 + (size_t)81 * ssie_round_up(B + 1, 64) * 128 + (size_t)kWgs * ssie_round_up(B + 1, 64);
+    // one slab area: kWgs slices of a 9-tap group over a 64 x 64 block (the Winograd weight gradient writes kWgs / 2 slices of 16
+    // transform positions: 8 per slice-pair < 9) + the per-layer remainder of the 9 x 9 / B+1-channel layers + the fused bias
+    // slabs + the Winograd dU[16][ci][co] scratch of the widest 3 x 3 layer (128 x 128, or 64 x (B+1))
+    const size_t du_max = (size_t)16 * 128 * (ssie_round_up(B + 1, 64) > 128 ? ssie_round_up(B + 1, 64) : 128);
+    pl.slab_cap = (size_t)kWgs * 9 * 64 * 64 + (size_t)81 * ssie_round_up(B + 1, 64) * 128 + (size_t)kWgs * ssie_round_up(B + 1, 64) + du_max;
     pl.slab_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + pl.slab_cap, 64);
     pl.slab_off2 = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + pl.slab_cap, 64);
     pl.partial_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 256 * 256, 64);
@@ -371,7 +381,9 @@ struct Builder {
         int rc = ssie_make_wgrad(p, x, pl.N * nbatch, Hv, Wv, 0, pl.buf(g), gb.cs, g_coff, L.cout, Ho, Wo, stride, t, pl.ws + soff, kWgs);
         if (rc) return rc;
         const size_t need = ssie_wgrad_slab_floats(p);
-        if (need + (size_t)p.nslices * p.co_pad > pl.slab_cap) return SSIE_E_WORKSPACE;
+        const size_t bneed = with_bias ? (size_t)p.nslices * p.co_pad : 0;
+        const size_t du_floats = p.wino ? (size_t)16 * creal * L.cout : 0;
+        if (need + bneed + du_floats > pl.slab_cap) return SSIE_E_WORKSPACE;     // before any op of this layer is pushed
         float* dw = pl.G + L.w + (size_t)ci_off * T;
         const long s_co = (long)L.cin * T;
         const float* slabs = pl.ws + soff;
@@ -382,17 +394,16 @@ struct Builder {
         const double fl = 2.0 * pl.N * nbatch * Ho * Wo * (double)cout * creal * T;
         char tag[96];
         snprintf(tag, sizeof(tag), "%swgrad ci%d co%d taps%d si%d %dx%d slices%d", p.wino ? "winograd " : "", creal, cout, T, stride, Ho, Wo, p.nslices);
-        ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_wgrad(p, st); }, p.wino ? K_WGRAD_WINO : K_WGRAD, fl, tag, sl));
+        ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_wgrad(p, st); }, p.wino ? K_WGRAD_WINO : K_WGRAD, fl, tag, sl, SLAB_WRITE));
         if (p.wino) {
-            // slabs -> dU[16][ci][co] (fixed-order sum over the slices; the fused bias gradient goes straight to its place) -> 9 taps
-            const size_t bneed = with_bias ? (size_t)p.nslices * p.co_pad : 0;
-            if (need + bneed + (size_t)16 * creal * cout > pl.slab_cap) return SSIE_E_WORKSPACE;
+            // slabs -> dU[16][ci][co] (fixed-order sum over the slices; the fused bias gradient goes straight to its place) -> 9 taps;
+            // dU lives in the same slab area, so the tap extraction is a slab reader too
             float* du = pl.ws + soff + need + bneed;
-            ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, p.nslices, 16, p.ci_pad, p.co_pad, creal, cout, du, 1, cout, (long)creal * cout, bslab, db, 0, st, 1); }, K_WGRAD_REDUCE, 0.0, "", sl));
-            ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_wino_out(du, creal, cout, dw, s_co, T, 1, 1, st); }, K_WGRAD_REDUCE, 0.0, "winograd wgrad: taps", sl));
+            ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, p.nslices, 16, p.ci_pad, p.co_pad, creal, cout, du, 1, cout, (long)creal * cout, bslab, db, 0, st, 1); }, K_WGRAD_REDUCE, 0.0, "", sl, SLAB_READ));
+            ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_wino_out(du, creal, cout, dw, s_co, T, 1, 1, st); }, K_WGRAD_REDUCE, 0.0, "winograd wgrad: taps", sl, SLAB_READ));
             return 0;
         }
-        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, p.nslices, p.ntaps, p.ci_pad, p.co_pad, creal, cout, dw, s_co, T, 1, bslab, db, 1, st); }, K_WGRAD_REDUCE, 0.0, "", sl));
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, p.nslices, p.ntaps, p.ci_pad, p.co_pad, creal, cout, dw, s_co, T, 1, bslab, db, 1, st); }, K_WGRAD_REDUCE, 0.0, "", sl, SLAB_READ));
         return 0;
     }
 
@@ -594,8 +605,8 @@ int build_decomposition_bwd(Builder& b, std::vector<Fn>& ops, const char* xin, i
         CK(ssie_make_wgrad(wp, gs, pl.N * 2, H, W, 0, pl.buf("c3_1"), cb.cs, 0, 128, H2, W2, 2, t, pl.ws + soff, kWgs));
         if (ssie_wgrad_slab_floats(wp) > pl.slab_cap) return SSIE_E_WORKSPACE;
         float* dw = pl.G + Ld.w; const float* slabs = pl.ws + soff;
-        ops.push_back(Fn([wp](hipStream_t st) { return ssie_launch_wgrad(wp, st); }, K_WGRAD, 2.0 * pl.N * 2 * H2 * W2 * 128.0 * 64 * 9, "", sl));
-        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, wp.nslices, wp.ntaps, wp.ci_pad, wp.co_pad, 64, 128, dw, 64L * 9, 9, 1, nullptr, nullptr, 1, st); }, K_WGRAD_REDUCE, 0.0, "", sl));
+        ops.push_back(Fn([wp](hipStream_t st) { return ssie_launch_wgrad(wp, st); }, K_WGRAD, 2.0 * pl.N * 2 * H2 * W2 * 128.0 * 64 * 9, "", sl, SLAB_WRITE));
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, wp.nslices, wp.ntaps, wp.ci_pad, wp.co_pad, 64, 128, dw, 64L * 9, 9, 1, nullptr, nullptr, 1, st); }, K_WGRAD_REDUCE, 0.0, "", sl, SLAB_READ));
     }
     if (wg) b.bias_grad(ops, Ld, "Gdc", 0, 2);
     {
@@ -698,6 +709,8 @@ int build_illum_bwd(Builder& b, std::vector<Fn>& ops)
     return 0;
 }
 
+int check_slab_flags(const std::vector<Fn>& ops);
+
 int build_all(Plan& pl, bool dry)
 {
     Builder b(pl, dry);
@@ -766,6 +779,7 @@ int build_all(Plan& pl, bool dry)
         push_tail(b, pl.fwdi);
     }
     pl.pack_floats_total = pl.pack_cursor;
+    CK(check_slab_flags(pl.lossbwd));
     return 0;
 }
 
@@ -793,22 +807,42 @@ int run_ops_overlapped(Plan& pl, std::vector<Fn>& ops, hipStream_t st)
             if (hipEventCreateWithFlags(&pl.ev_w[i], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&pl.ev_r[i], hipEventDisableTiming) != hipSuccess) return SSIE_E_LAUNCH;
     }
+    // the stream order is derived from each op's slab_use flag alone; every event call is checked - a failed record / wait
+    // would silently drop an ordering edge, i.e. turn into wrong gradients instead of an error
     bool pending[2] = {false, false};
     int rc = 0;
+    auto ok = [&](hipError_t e) { if (e != hipSuccess) rc = SSIE_E_LAUNCH; return e == hipSuccess; };
     for (auto& f : ops) {
-        if (f.kind == K_WGRAD || f.kind == K_WGRAD_WINO) {
-            if (pending[f.slab]) { hipStreamWaitEvent(st, pl.ev_r[f.slab], 0); pending[f.slab] = false; }
+        if (f.slab_use == SLAB_WRITE) {
+            if (pending[f.slab]) { if (!ok(hipStreamWaitEvent(st, pl.ev_r[f.slab], 0))) break; pending[f.slab] = false; }
             if (f(st)) { rc = SSIE_E_LAUNCH; break; }
-            hipEventRecord(pl.ev_w[f.slab], st);
-        } else if (f.kind == K_WGRAD_REDUCE) {
-            hipStreamWaitEvent(pl.side, pl.ev_w[f.slab], 0);
+            if (!ok(hipEventRecord(pl.ev_w[f.slab], st))) break;
+        } else if (f.slab_use == SLAB_READ) {
+            if (!ok(hipStreamWaitEvent(pl.side, pl.ev_w[f.slab], 0))) break;
             if (f(pl.side)) { rc = SSIE_E_LAUNCH; break; }
-            hipEventRecord(pl.ev_r[f.slab], pl.side);
-            pending[f.slab] = true;
+            pending[f.slab] = true;               // set before the record: the join below must cover this launch either way
+            if (!ok(hipEventRecord(pl.ev_r[f.slab], pl.side))) break;
         } else if (f(st)) { rc = SSIE_E_LAUNCH; break; }
     }
-    for (int i = 0; i < 2; ++i) if (pending[i]) hipStreamWaitEvent(st, pl.ev_r[i], 0);   // join (also on the error path)
+    if (rc) {
+        // error path: the event chain may be incomplete, so join the side stream the blunt way before reporting
+        hipStreamSynchronize(pl.side);
+        return rc;
+    }
+    for (int i = 0; i < 2; ++i) if (pending[i] && hipStreamWaitEvent(st, pl.ev_r[i], 0) != hipSuccess) rc = SSIE_E_LAUNCH;
     return rc;
+}
+
+// every op that touches a slab area must say so: a weight-gradient kind without SLAB_WRITE or a reduction kind without
+// SLAB_READ would race the side stream (this round's ADVICE: the round-2 failure was exactly a kind missing from a list)
+int check_slab_flags(const std::vector<Fn>& ops)
+{
+    for (auto& f : ops) {
+        const bool w = f.kind == K_WGRAD || f.kind == K_WGRAD_WINO, r = f.kind == K_WGRAD_REDUCE;
+        if ((w && f.slab_use != SLAB_WRITE) || (r && f.slab_use != SLAB_READ) || (!w && !r && f.slab_use != SLAB_NONE)) return SSIE_E_ARG;
+        if (f.slab < 0 || f.slab > 1) return SSIE_E_ARG;
+    }
+    return 0;
 }
 
 } // namespace
@@ -827,6 +861,10 @@ extern "C" void* ssie_plan_create(int N, int bands, int H, int W, const float* c
     for (int i = 0; i < 8; ++i) pl->coefs[i] = coefs8 ? coefs8[i] : 0.f;
     build_params(*pl);
     build_buffers(*pl);
+    // the kernels address activations with 32-bit element offsets, and the weight gradients run over [pass 1 ; pass 2] pairs of 2N
+    // patches: no plan whose largest tensor reaches 2^31 floats (every BASELINE config stays below 2^29)
+    for (auto& kv : pl->bufs)
+        if (!ssie_fits_i32(2L * kv.second.N, kv.second.H, kv.second.W, kv.second.cs)) { delete pl; return nullptr; }
     // aliases of tmpH with the lower-resolution geometries
     BufInfo t = pl->bufs["tmpH"];
     BufInfo t2 = t; t2.H = pl->H2; t2.W = pl->W2; pl->bufs["tmpH2"] = t2;

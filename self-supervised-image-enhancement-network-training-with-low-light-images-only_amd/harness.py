@@ -9,7 +9,8 @@ redesigned for the GPU path:
     only the crop coordinates come from the host RNG, drawn in the reference's order
     (`np.random.randint(0, h-patch)`, `(0, w-patch)`, `(0, 8)` per sample, model.py:306-308);
   * the train step is the fused `LowLightEnhance.train_step` (no autograd, one RCCL all-reduce when world > 1);
-    the loss scalars are read back once per epoch-batch print like the reference's `loss.item()`;
+    the loss scalars are read back with a one-step lag through a pinned ring (`LaggedScalars`): the same per-batch print as
+    the reference's `loss.item()`, without its per-step synchronisation;
   * the Linux-only defects of the reference are fixed: checkpoints are written to AND read from
     `.../Decomposition_<timestamp>` (main.py:87 looks for `decomposition_`), evaluation reads the key it wrote
     (`data`, model.py:375 vs :395), file names are split with os.path.basename (metrics.py:111 splits on '\\\\').
@@ -133,6 +134,11 @@ def _to_device_cubes(cubes, device):
     return [torch.from_numpy(np.ascontiguousarray(c)).to(device) for c in cubes]
 
 
+def ctypes_sizeof_crop() -> int:
+    import ctypes
+    return ctypes.sizeof(H.CropT)
+
+
 def draw_crops(n_cubes, shapes, batch_id, batch_size, patch, rng=np.random):
     """(cube index, x0, y0, mode) per sample, in the reference's RNG order (model.py:304-308)."""
     out = []
@@ -144,6 +150,45 @@ def draw_crops(n_cubes, shapes, batch_id, batch_size, patch, rng=np.random):
         x0 = int(rng.randint(0, h - patch)); y0 = int(rng.randint(0, w - patch)); mode = int(rng.randint(0, 8))
         out.append((idx, x0, y0, mode))
     return out
+
+
+class LaggedScalars:
+    """Loss read-back that does not stall the launch loop (SURVEY §8(f) N1 "async loss logging"; the reference blocks on seven
+    `.item()` calls per step, model.py:566-574).  After every step the 7 device scalars are copied into a slot of a pinned ring
+    on the compute stream and an event is recorded; the host consumes step i only after step i+1 has been enqueued, so it
+    waits for a step that is already finished (or finishing) while the device has the next one queued.  Values, order and
+    count of what the caller sees are exactly those of the blocking read - only one step later."""
+
+    def __init__(self, depth: int = 2):
+        self.depth = max(2, int(depth))
+        self.host = torch.empty(self.depth, 8, dtype=torch.float32, pin_memory=True)
+        self.events = [torch.cuda.Event() for _ in range(self.depth)]
+        self.pending = []                     # [(slot, tag)] oldest first
+        self.n = 0
+
+    def _take(self):
+        slot, tag = self.pending.pop(0)
+        self.events[slot].synchronize()
+        return tag, self.host[slot, :7].numpy().copy()
+
+    def push(self, scalars: torch.Tensor, tag):
+        """enqueue the read-back of this step; returns the [(tag, values)] that are now due (everything but the newest)"""
+        out = []
+        while len(self.pending) >= self.depth:            # never overwrite a slot that has not been consumed
+            out.append(self._take())
+        slot = self.n % self.depth; self.n += 1
+        self.host[slot, :7].copy_(scalars.detach().reshape(-1)[:7], non_blocking=True)
+        self.events[slot].record()
+        self.pending.append((slot, tag))
+        while len(self.pending) > 1:
+            out.append(self._take())
+        return out
+
+    def drain(self):
+        out = []
+        while self.pending:
+            out.append(self._take())
+        return out
 
 
 def train_model(net, train_data_path, eval_data_path, batch_size, patch_size, num_epochs, ckpt_dir, eval_result_dir,
@@ -168,19 +213,32 @@ def train_model(net, train_data_path, eval_data_path, batch_size, patch_size, nu
     num_batches = len(train_np) // batch_size
     mine = dp.shard_range(batch_size, rank, world)
     dp.broadcast_flat_(net.flat_parameters(), world)
+    # no per-step host<->device synchronisation: crop records go up through a pinned two-slot ring (slot i is reused at step
+    # i + 2, after the lagged read-back below has waited for step i), loss scalars come back one step late
+    lag = LaggedScalars(2)
+    nrec = max(len(mine), 1) * ctypes_sizeof_crop()
+    staging = [torch.empty(nrec, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+    step_no = 0
     for epoch in range(num_epochs):
         # DecompositionNet freeze / unfreeze (model.py:274-288)
         frozen = getattr(net, "freeze_decom_epochs", 0) > 0 and epoch < net.freeze_decom_epochs
         net.set_decomposition_frozen(frozen)
         sums = np.zeros(7); count = 0
+
+        def consume(items):
+            nonlocal sums, count
+            for (ep, bb), vals in items:
+                sums += vals; count += 1
+                if rank == 0:
+                    log(f"Epoch [{ep + 1}/{num_epochs}] Batch [{bb + 1}/{num_batches}] Loss: {vals[0]:.6f}")
+
         for b in range(num_batches):
             crops = draw_crops(len(cubes), shapes, b, batch_size, patch_size)       # same draws on every rank (same seed)
-            x = H.assemble_batch(cubes, [crops[i] for i in mine], patch_size, net.input_channels)
+            x = H.assemble_batch(cubes, [crops[i] for i in mine], patch_size, net.input_channels, staging=staging[step_no & 1])
+            step_no += 1
             scal = net.train_step(x, world)
-            vals = scal.detach().cpu().numpy()
-            sums += vals; count += 1
-            if rank == 0:
-                log(f"Epoch [{epoch + 1}/{num_epochs}] Batch [{b + 1}/{num_batches}] Loss: {vals[0]:.6f}")
+            consume(lag.push(scal, (epoch, b)))
+        consume(lag.drain())                                  # epoch boundary: means, evaluation and checkpoints see every step
         means = sums / max(count, 1)
         for k, v in zip(LOSS_KEYS, means):
             net.all_epoch_losses[k].append(float(v))

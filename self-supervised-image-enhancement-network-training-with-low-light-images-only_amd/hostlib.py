@@ -371,9 +371,11 @@ class CropT(C.Structure):
     _fields_ = [("cube", C.c_void_p), ("H", C.c_int), ("W", C.c_int), ("x0", C.c_int), ("y0", C.c_int), ("mode", C.c_int)]
 
 
-def assemble_batch(cubes, crops, patch: int, bands: int) -> torch.Tensor:
-    """cubes: list of (H,W,C) fp32 cuda tensors; crops: [(cube index, x0, y0, mode)] -> logical (n, C, P, P) channels_last batch"""
-    import numpy as np
+def assemble_batch(cubes, crops, patch: int, bands: int, staging: torch.Tensor | None = None) -> torch.Tensor:
+    """cubes: list of (H,W,C) fp32 cuda tensors; crops: [(cube index, x0, y0, mode)] -> logical (n, C, P, P) channels_last batch.
+    staging: a PINNED uint8 host tensor of >= n * sizeof(CropT) bytes the caller keeps alive (and does not overwrite) until the
+    copy has run: the crop records then go up with a non-blocking H2D on the current stream instead of a pageable copy, which
+    would synchronise the host with everything queued on the stream (harness.train_model passes a two-slot ring)."""
     n = len(crops)
     dev = cubes[0].device
     recs = (CropT * n)()
@@ -382,7 +384,14 @@ def assemble_batch(cubes, crops, patch: int, bands: int) -> torch.Tensor:
         assert cb.is_contiguous() and cb.dtype == torch.float32 and cb.shape[2] == bands
         assert 0 <= x0 <= cb.shape[0] - patch and 0 <= y0 <= cb.shape[1] - patch and 0 <= mode < 8
         recs[i] = CropT(cb.data_ptr(), cb.shape[0], cb.shape[1], x0, y0, mode)
-    raw = torch.frombuffer(bytearray(bytes(recs)), dtype=torch.uint8).to(dev)
+    nb = C.sizeof(recs)
+    if staging is not None:
+        if not (staging.is_pinned() and staging.dtype == torch.uint8 and staging.numel() >= nb):
+            raise SsieError("assemble_batch: staging must be a pinned uint8 tensor large enough for the crop records")
+        C.memmove(staging.data_ptr(), C.addressof(recs), nb)
+        raw = staging[:nb].to(dev, non_blocking=True)
+    else:
+        raw = torch.frombuffer(bytearray(bytes(recs)), dtype=torch.uint8).to(dev)
     cs = (bands + 3) // 4 * 4
     out = torch.empty(n, patch, patch, cs, device=dev)
     check(lib().ssie_assemble_batch(ptr(raw), n, ptr(out), patch, bands, cs, stream_ptr()), "ssie_assemble_batch")

@@ -87,3 +87,34 @@ def test_module_surface_matches_reference(pkg):
         assert torch.equal(v, P[k])
     with pytest.raises(H.SsieError):
         net(torch.zeros(1, 31, 16, 16))          # CPU tensors: loud failure, no fallback
+
+
+def test_32bit_offset_guard(pkg):
+    """The kernels index activations with 32-bit element offsets: a plan / operator whose largest tensor reaches 2^31 floats
+    must be refused on the host (NULL / SSIE_E_SHAPE) instead of wrapping into a GPU fault.  No kernel is launched: geometry
+    is rejected before anything is enqueued (the pointers below are fakes)."""
+    H, _ = pkg
+    L = H._proto()
+    cf = (ctypes.c_float * 8)(*[1.0] * 8)
+    # BASELINE sizes are far inside the limit: N = 32 at 128 x 128 x 256 is 2 * 32 * 128 * 128 * 260 = 2.7e8 floats
+    for ok in ((32, 31, 128, 128), (32, 256, 128, 128), (1, 31, 1024, 1024), (200, 31, 128, 128)):
+        h = L.ssie_plan_create(*ok, cf)
+        assert h, ok
+        L.ssie_plan_destroy(h)
+    # 2N * H * W * 64 >= 2^31  <=>  N >= 1024 at 128 x 128; one 4096 x 4096 image is 2 * 4096^2 * 64 = 2^31 exactly
+    for bad in ((1024, 31, 128, 128), (1, 31, 4096, 4096), (64, 256, 256, 256), (1 << 20, 31, 128, 128)):
+        assert not L.ssie_plan_create(*bad, cf), bad
+    assert L.ssie_plan_create(1023, 31, 128, 128, cf)
+    # granular operators: SSIE_E_SHAPE (2) from the geometry builder, before any launch
+    fake = ctypes.c_void_p(1 << 20)
+    src = H.SrcT(1 << 20, 64, 64, 0, 128, 128)
+    n_bad = 2048 + 1                                              # 2049 * 128 * 128 * 64 > 2^31 - 1
+    ws_bytes = ctypes.c_size_t(1 << 30)
+    rc = L.ssie_conv2d_fwd(ctypes.byref(src), 1, n_bad, 128, 128, fake, 64, fake, 64, 3, 1, 0, None, None, fake, 64, 0,
+                           fake, ws_bytes, None)
+    assert rc == 2, rc
+    rc = L.ssie_conv2d_wgrad(ctypes.byref(src), n_bad, 128, 128, fake, 64, 0, 64, 3, 1, 64, 0, fake, fake, 0, fake, ws_bytes, None)
+    assert rc == 2, rc
+    rc = L.ssie_conv2d_dgrad(fake, 64, 0, n_bad, 128, 128, 64, fake, 64, 0, 64, 3, 1, fake, 128, 128, 64, 0, None, 0, 0,
+                             fake, ws_bytes, None)
+    assert rc == 2, rc

@@ -159,3 +159,35 @@ def test_reference_method_names(M, tmp_path, monkeypatch):
     # evaluate_model positional, as model.py:328 calls it
     net.evaluate_model(data, names, str(tmp_path / "evalres2"), 7, str(tmp_path / "high"))
     assert (tmp_path / "evalres2" / "epoch_7" / "t.mat").exists() and 7 in net.eval_metrics
+
+
+def test_lagged_loss_readback(M):
+    """harness.LaggedScalars (async loss logging): the values, order and count of the blocking read-back
+    (model.py:566-574), one step late, with no slot overwritten before it was consumed; and the pinned crop-record staging of
+    ssie_assemble_batch gives the same batch as the pageable path."""
+    import ssie
+    ssie.load()
+    from ssie_amd import harness, hostlib
+    lag = harness.LaggedScalars(2)
+    dev = torch.device("cuda", 0)
+    scal = torch.zeros(16, device=dev)                      # ONE device buffer rewritten every step, like the plan's
+    seen = []
+    for i in range(7):
+        scal[:7] = torch.arange(7, device=dev, dtype=torch.float32) + 100.0 * i
+        due = lag.push(scal, ("e", i))
+        assert len(due) == (0 if i == 0 else 1)             # exactly the previous step becomes due
+        seen += due
+    seen += lag.drain()
+    assert [t for t, _ in seen] == [("e", i) for i in range(7)]
+    for i, (_, v) in enumerate(seen):
+        assert v.shape == (7,) and np.array_equal(v, np.arange(7, dtype=np.float32) + 100.0 * i)
+    assert lag.drain() == []
+    cube = torch.rand(40, 48, 8, device=dev)
+    crops = [(0, 3, 5, 2), (0, 7, 1, 7), (0, 0, 15, 0)]
+    a = hostlib.assemble_batch([cube], crops, 32, 8)
+    st = torch.empty(len(crops) * harness.ctypes_sizeof_crop(), dtype=torch.uint8, pin_memory=True)
+    b = hostlib.assemble_batch([cube], crops, 32, 8, staging=st)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    with pytest.raises(hostlib.SsieError):
+        hostlib.assemble_batch([cube], crops, 32, 8, staging=torch.empty(4, dtype=torch.uint8, pin_memory=True))
