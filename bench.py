@@ -16,8 +16,9 @@ workloads (BASELINE.json configs):
 The default invocation (`python bench.py`, 1 GPU, headline workload) also runs SHORT passes of the other two single-GPU BASELINE
 configs after the headline has been timed - train256 (3 warm-up + 5 steps) and infer1024_bf16 (5 + 20) - and attaches them
 as `"also": [{workload, value, unit, ms_per_step, parity, roofline, ...}]`; the headline fields are untouched (`--no-also`
-skips them).  `host_ms_per_step` = host time spent INSIDE the train_step calls of the timed region (Python + launch enqueue,
-no synchronisation): what one CPU core must sustain per step to keep a GPU fed.
+skips them).  `host_ms_per_step` = host time spent INSIDE one train_step call of the timed region (Python + launch enqueue,
+no synchronisation; minimum over the steps = a step that did not block on a full HIP queue): what one CPU core must sustain
+per step to keep a GPU fed.
 
 Rank 0 prints ONE JSON line.  `value` = units/s over all ranks, max-over-ranks time around exactly K steps.
 `roofline` = the dominant kernel class by device time, from HIP events recorded after every launch in a profiled pass of
@@ -123,11 +124,11 @@ def run_train(args, torch, dist, hostlib, model, world, rank, dev):
             first = (scal.clone(), net._plan_for(x).nchw("S", 0, bands).clone())
     sync_all()
     t0 = time.perf_counter()
-    host = 0.0
+    host = []
     for _ in range(args.steps):
         h0 = time.perf_counter()
         net.train_step(x, world)
-        host += time.perf_counter() - h0
+        host.append(time.perf_counter() - h0)
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -146,9 +147,10 @@ def run_train(args, torch, dist, hostlib, model, world, rank, dev):
                    "global_batch": world * batch, "parallelism": f"dp{world}" if world > 1 else "single",
                    "weights": "random init (PyTorch default), seed 41"},
         "final_total_loss": losses[0],
-        # host time inside the train_step calls (Python + HIP launch enqueue, no sync) per step: the launch loop runs ahead of
-        # the device, so this - not ms_per_step - is what the host side costs
-        "host_ms_per_step": round(host / args.steps * 1e3, 3),
+        # host time inside the train_step calls (Python + HIP launch enqueue, no sync) per step.  The launch loop runs ahead of the
+        # device until the HIP queue is full and then blocks in the enqueue, so the MEAN contains that back-pressure wait; the
+        # MINIMUM over the timed steps is an un-blocked step = what the host side actually costs per step
+        "host_ms_per_step": round(min(host) * 1e3, 3), "host_ms_per_step_mean_incl_queue_backpressure": round(sum(host) / args.steps * 1e3, 3),
     }
     gf = GFLOP_PER_PATCH.get((bands, hw))
     if gf:
