@@ -37,6 +37,8 @@ void ssie_debug_set_fprop_v2_split_min_tiles(int v);    /* [1024] */
 void ssie_debug_set_fprop_wgs_per_cu(int v);
 void ssie_debug_set_tconv(int v);                       /* [1] 0 = stride-2 transposed 3x3 convolutions always as four output-parity launches (plans created afterwards) */
 void ssie_debug_set_tconv_min_tiles(int v);             /* [256] fewest 16x16 input tiles for the one-launch kernel */
+void ssie_debug_set_fft_grouped(int v);                 /* [1] 0 = Fourier loss planes that fit the LDS always run the whole-plane kernel (fft_loss_kernel); plans / operator calls made afterwards */
+void ssie_debug_set_loss_chunked(int v);                /* [0] 1 = the band-chunked tiled loss kernel (loss_chunk_kernel, normally only above 252 bands) for every band count */
 void ssie_debug_set_wino(int v);                        /* [1] 0 = stride-1 3x3 launches never run the Winograd F(2x2,3x3) kernel (plans created afterwards) */
 void ssie_debug_set_wino_min_tiles(int v);
 void ssie_debug_set_wgrad_wino(int v);                  /* [1] 0 = stride-1 3x3 weight gradients never run the Winograd F(3x3,2x2) kernel (plans created afterwards) */

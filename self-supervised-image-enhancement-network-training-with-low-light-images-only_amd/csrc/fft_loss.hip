@@ -23,14 +23,14 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(
 // natural in / bit-reversed out; inverse: decimation in time on the bit-reversed layout), so results are unchanged.
 // Lanes run over LINES first: row passes then touch addresses (W+1)*8 B apart and column passes 8 B apart, both
 // bank-conflict free, and all lanes of a wave share each twiddle (LDS broadcast).
-template <bool INVERSE, int R>
+template <bool INVERSE, int R, int NT = FFT_THREADS>
 __device__ __forceinline__ void fft_block(float2* z, const float2* tw, int logM, int n, int logn, int lines, int loglines,
                                           int es, int ls, int tid, int st0)
 {
     constexpr int RR = 1 << R;
     const int lo = INVERSE ? st0 : logn - st0 - R;          // lowest of the R index bits handled here
     const int items = lines * (n >> R);
-    for (int id = tid; id < items; id += FFT_THREADS) {
+    for (int id = tid; id < items; id += NT) {
         const int line = id & (lines - 1), g = id >> loglines;
         const int base = ((g >> lo) << (lo + R)) | (g & ((1 << lo) - 1));
         float2* zl = z + line * ls;
@@ -67,16 +67,16 @@ __device__ __forceinline__ void fft_block(float2* z, const float2* tw, int logM,
 }
 
 // all log2(n) stages of `lines` transforms (element stride es, line stride ls), four stages per LDS round trip
-template <bool INVERSE>
+template <bool INVERSE, int NT = FFT_THREADS>
 __device__ __forceinline__ void fft_pass(float2* z, const float2* tw, int logM, int n, int logn, int lines, int loglines,
                                          int es, int ls, int tid)
 {
     int st = 0;
-    for (; logn - st >= 4; st += 4) fft_block<INVERSE, 4>(z, tw, logM, n, logn, lines, loglines, es, ls, tid, st);
+    for (; logn - st >= 4; st += 4) fft_block<INVERSE, 4, NT>(z, tw, logM, n, logn, lines, loglines, es, ls, tid, st);
     switch (logn - st) {
-    case 3: fft_block<INVERSE, 3>(z, tw, logM, n, logn, lines, loglines, es, ls, tid, st); break;
-    case 2: fft_block<INVERSE, 2>(z, tw, logM, n, logn, lines, loglines, es, ls, tid, st); break;
-    case 1: fft_block<INVERSE, 1>(z, tw, logM, n, logn, lines, loglines, es, ls, tid, st); break;
+    case 3: fft_block<INVERSE, 3, NT>(z, tw, logM, n, logn, lines, loglines, es, ls, tid, st); break;
+    case 2: fft_block<INVERSE, 2, NT>(z, tw, logM, n, logn, lines, loglines, es, ls, tid, st); break;
+    case 1: fft_block<INVERSE, 1, NT>(z, tw, logM, n, logn, lines, loglines, es, ls, tid, st); break;
     default: break;
     }
 }
@@ -201,10 +201,15 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_loss_kernel(const FftParams p
 }
 
 // ---------------------------------------------------------------------------------------------
-// Planes that do not fit the LDS (training patches above 128 x 128, model.py:456-473 accepts any patch_size):
-// three passes over a half-spectrum workspace in HBM, every pass a batch of independent 1-D transforms in LDS.
+// Three passes over a half-spectrum workspace, every pass a batch of independent 1-D transforms in LDS.  Two users:
+//   * planes that do not fit the LDS (training patches above 128 x 128, model.py:456-473 accepts any patch_size)
+//   * BAND-GROUPED rows (fft_rows_*_grouped_kernel, power-of-two W, planes of 64 x 64 and more): the tensors are NHWC, so a
+//     workgroup that owns ONE band plane reads 4 bytes per 128-byte line - measured, that gather (3.7 cycles per element and CU)
+//     is what the whole-plane kernel above spends its time on, not the transform.  Passes A and C therefore take BG = 16
+//     neighbouring bands of R image rows at once: 64 contiguous bytes per pixel in, 64 contiguous bytes per pixel out.
 //   A  rows:    Z = FFT_W(x + i S) per row, split into the row spectra X^[h][kx], S^[h][kx] of the two REAL inputs,
-//               kx = 0..W/2 only (the other half is the conjugate), stored column-major  ws[plane][a][kx][h]
+//               kx = 0..W/2 only (the other half is the conjugate), stored row-major  ws[plane][a][h][kx]  (pass A writes runs of
+//               W/2+1 bins, pass B reads CB = 16 neighbouring columns of a row as one 128-byte run)
 //   B  columns: FFT_H of both -> F(x)[ky][kx], F(S)[ky][kx]; loss + g_Z per bin, weighted by M[k] + M[-k] on the interior
 //               columns (the mirror bin (-ky, W-kx) lives in the dropped half and has the same magnitudes; Re() of the
 //               adjoint makes its contribution the conjugate's - SURVEY §2.1 "cannot simply double"); inverse FFT_H
@@ -212,11 +217,11 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_loss_kernel(const FftParams p
 //   C  rows:    gS[h][w] += Re sum_{kx <= W/2} G^[kx][h] e^{+2 pi i kx w / W}  (complex inverse with the upper half zero)
 // Power-of-two lengths use the radix-2 passes above, other lengths the direct DFT (out of place, any length).
 // ---------------------------------------------------------------------------------------------
-template <bool INVERSE>
+template <bool INVERSE, int NT = FFT_THREADS>
 __device__ __forceinline__ void dft_lines(const float2* src, float2* dst, const float2* tw, int n, int lines, int es, int ls, int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
-    for (int line = wave; line < lines; line += FFT_THREADS / 64) {
+    for (int line = wave; line < lines; line += NT / 64) {
         const float2* sl = src + line * ls; float2* dl = dst + line * ls;
         for (int j0 = 0; j0 < n; j0 += 64) {
             const int j = j0 + lane, jj = j % n;
@@ -236,14 +241,16 @@ __device__ __forceinline__ void dft_lines(const float2* src, float2* dst, const 
     __syncthreads();
 }
 
+template <int NT = FFT_THREADS>
 __device__ __forceinline__ void fill_twiddles(float2* tw, int n, int count, int tid)
 {
-    for (int t = tid; t < count; t += FFT_THREADS) { float sn, cs; sincospif(-2.0f * (float)t / (float)n, &sn, &cs); tw[t] = make_float2(cs, sn); }
+    for (int t = tid; t < count; t += NT) { float sn, cs; sincospif(-2.0f * (float)t / (float)n, &sn, &cs); tw[t] = make_float2(cs, sn); }
 }
 
 __device__ __forceinline__ int brev_n(int v, int logn) { return (int)(__brev((unsigned)v) >> (32 - logn)); }
 
-struct FftBigGeom { int R, logR, CB, logCB, WH, plane0, nplanes, row_tiles, col_groups; };
+struct FftBigGeom { int R, logR, CB, logCB, WH, plane0, nplanes, row_tiles, col_groups;
+                    int BG, logBG, groups, patch0, npatches; };        // band-grouped passes A / C: BG bands per workgroup, whole patches per chunk
 
 // pass A.  grid = nplanes * row_tiles
 __global__ __launch_bounds__(FFT_THREADS) void fft_rows_fwd_kernel(const FftParams p, const FftBigGeom g)
@@ -271,18 +278,64 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_rows_fwd_kernel(const FftPara
     float2* wsx = (float2*)p.ws + (size_t)pl * 2 * g.WH * H;
     float2* wss = wsx + (size_t)g.WH * H;
     for (int id = tid; id < R * g.WH; id += FFT_THREADS) {
-        const int r = id & (R - 1), kx = id >> g.logR, h = h0 + r;         // lanes along h: contiguous stores
+        const int r = id / g.WH, kx = id - r * g.WH, h = h0 + r;           // lanes along kx: contiguous stores
         if (h >= H) continue;
         const int qx = kx ? W - kx : 0;
         const float2 Zk = zo[r * LS + (pow2 ? brev_n(kx, p.logW) : kx)], Zm = zo[r * LS + (pow2 ? brev_n(qx, p.logW) : qx)];
-        wsx[(size_t)kx * H + h] = make_float2(0.5f * (Zk.x + Zm.x), 0.5f * (Zk.y - Zm.y));
-        wss[(size_t)kx * H + h] = make_float2(0.5f * (Zk.y + Zm.y), -0.5f * (Zk.x - Zm.x));
+        wsx[(size_t)h * g.WH + kx] = make_float2(0.5f * (Zk.x + Zm.x), 0.5f * (Zk.y - Zm.y));
+        wss[(size_t)h * g.WH + kx] = make_float2(0.5f * (Zk.y + Zm.y), -0.5f * (Zk.x - Zm.x));
     }
 }
 
-// pass B.  grid = nplanes * col_groups
-__global__ __launch_bounds__(FFT_THREADS) void fft_cols_kernel(const FftParams p, const FftBigGeom g)
+// pass A, band-grouped (power-of-two W).  grid = npatches * groups * row_tiles; LDS lines = BG bands x R rows.  512 threads: 64
+// lines of 128 points are 512 four-stage items; the 66 KB footprint lets two workgroups share a CU
+#define FFT_ROWS_THREADS 512
+template <int BG>
+__global__ __launch_bounds__(FFT_ROWS_THREADS) void fft_rows_fwd_grouped_kernel(const FftParams p, const FftBigGeom g)
 {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    constexpr int Q = BG / 4, NT = FFT_ROWS_THREADS;                          // float4s per pixel of the band group
+    const int tid = threadIdx.x, H = p.H, W = p.W, LS = W + 1, R = g.R;
+    const int per = g.groups * g.row_tiles;
+    const int pn = blockIdx.x / per, rem = blockIdx.x - pn * per, cg = rem / g.row_tiles, rt = rem - cg * g.row_tiles;
+    const int n = g.patch0 + pn, c0 = cg * BG, h0 = rt * R;
+    float2* z = (float2*)smem_f;                       // [BG * R][W+1], line = band * R + row
+    float2* tw = z + BG * R * LS;
+    fill_twiddles<NT>(tw, W, W >> 1, tid);
+    const size_t base = (size_t)n * H * W;
+    for (int id = tid; id < R * W * Q; id += NT) {
+        const int q = id % Q, px = id / Q, r = px >> p.logW, w = px & (W - 1), h = h0 + r, c = c0 + 4 * q;
+        f32x4 xv = {0.f, 0.f, 0.f, 0.f}, sv = xv;
+        if (h < H && c < p.x_cs) {                     // x_cs is a multiple of 4: the whole float4 is inside the pixel's band vector
+            const size_t pix = base + (size_t)h * W + w;
+            xv = *(const f32x4*)(p.x + pix * p.x_cs + c); sv = *(const f32x4*)(p.S + pix * p.s_cs + c);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            z[((4 * q + j) * R + r) * LS + w] = (c + j < p.B) ? make_float2(xv[j], sv[j]) : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    fft_pass<false, NT>(z, tw, p.logW, W, p.logW, BG * R, g.logBG + g.logR, 1, LS, tid);
+    const size_t pf = (size_t)2 * g.WH * H;            // complex elements per plane in the workspace
+    for (int id = tid; id < BG * R * g.WH; id += NT) {
+        const int line = id / g.WH, kx = id - line * g.WH, b = line >> g.logR, r = line & (R - 1), h = h0 + r;
+        if (h >= H || c0 + b >= p.B) continue;
+        float2* wsx = (float2*)p.ws + ((size_t)pn * p.B + c0 + b) * pf;
+        float2* wss = wsx + (size_t)g.WH * H;
+        const int qx = kx ? W - kx : 0;
+        const float2 Zk = z[line * LS + brev_n(kx, p.logW)], Zm = z[line * LS + brev_n(qx, p.logW)];
+        wsx[(size_t)h * g.WH + kx] = make_float2(0.5f * (Zk.x + Zm.x), 0.5f * (Zk.y - Zm.y));
+        wss[(size_t)h * g.WH + kx] = make_float2(0.5f * (Zk.y + Zm.y), -0.5f * (Zk.x - Zm.x));
+    }
+}
+
+// pass B.  grid = nplanes * col_groups.  256 threads: a workgroup transforms 2 * CB = 32 columns of 128 points at a time, i.e. 256
+// four-stage items - with 1024 threads seven of eight sat out every stage block (102 -> see DESIGN.md for the measured effect);
+// the LDS footprint (33 KB) lets four such workgroups share a CU
+#define FFT_COLS_THREADS 256
+__global__ __launch_bounds__(FFT_COLS_THREADS) void fft_cols_kernel(const FftParams p, const FftBigGeom g)
+{
+    constexpr int NT = FFT_COLS_THREADS;
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     const int tid = threadIdx.x, H = p.H, W = p.W, LS = H + 1, CB = g.CB;
     const int pl = blockIdx.x / g.col_groups, cg = blockIdx.x % g.col_groups, kx0 = cg * CB;
@@ -292,21 +345,22 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols_kernel(const FftParams p
     float2* a2 = b + CB * LS; float2* b2 = a2 + CB * LS;      // direct DFT only
     float2* tw = pow2 ? a2 : b2 + CB * LS;
     float* red = (float*)(tw + (pow2 ? (H >> 1) : H));
-    fill_twiddles(tw, H, pow2 ? (H >> 1) : H, tid);
+    fill_twiddles<NT>(tw, H, pow2 ? (H >> 1) : H, tid);
     float2* wsx = (float2*)p.ws + (size_t)pl * 2 * g.WH * H;
     float2* wss = wsx + (size_t)g.WH * H;
-    for (int id = tid; id < CB * H; id += FFT_THREADS) {
-        const int col = id / H, h = id - col * H, kx = kx0 + col;
+#pragma unroll 4
+    for (int id = tid; id < CB * H; id += NT) {
+        const int h = id >> g.logCB, col = id & (CB - 1), kx = kx0 + col;      // lanes along the CB columns: one 128-byte run per row
         float2 va = make_float2(0.f, 0.f), vb = va;
-        if (kx < g.WH) { va = wsx[(size_t)kx * H + h]; vb = wss[(size_t)kx * H + h]; }
+        if (kx < g.WH) { va = wsx[(size_t)h * g.WH + kx]; vb = wss[(size_t)h * g.WH + kx]; }
         a[col * LS + h] = va; b[col * LS + h] = vb;
     }
     __syncthreads();
     float2* fa = a; float2* fb = b;
-    if (pow2) { fft_pass<false>(a, tw, p.logH, H, p.logH, CB, g.logCB, 1, LS, tid); fft_pass<false>(b, tw, p.logH, H, p.logH, CB, g.logCB, 1, LS, tid); }
-    else { dft_lines<false>(a, a2, tw, H, CB, 1, LS, tid); dft_lines<false>(b, b2, tw, H, CB, 1, LS, tid); fa = a2; fb = b2; }
+    if (pow2) fft_pass<false, NT>(a, tw, p.logH, H, p.logH, 2 * CB, g.logCB + 1, 1, LS, tid);      // a and b are adjacent: 2 CB lines in one go
+    else { dft_lines<false, NT>(a, a2, tw, H, CB, 1, LS, tid); dft_lines<false, NT>(b, b2, tw, H, CB, 1, LS, tid); fa = a2; fb = b2; }
     float lsum = 0.f;
-    for (int id = tid; id < CB * H; id += FFT_THREADS) {
+    for (int id = tid; id < CB * H; id += NT) {
         const int col = id / H, ky = id - col * H, kx = kx0 + col;
         const int pos = col * LS + (pow2 ? brev_n(ky, p.logH) : ky);
         float2 G = make_float2(0.f, 0.f);
@@ -324,18 +378,18 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols_kernel(const FftParams p
     }
     __syncthreads();
     const float2* go = fb;
-    if (pow2) fft_pass<true>(fb, tw, p.logH, H, p.logH, CB, g.logCB, 1, LS, tid);
-    else { dft_lines<true>(fb, b, tw, H, CB, 1, LS, tid); go = b; }
-    for (int id = tid; id < CB * H; id += FFT_THREADS) {
-        const int col = id / H, h = id - col * H, kx = kx0 + col;
-        if (kx < g.WH) wss[(size_t)kx * H + h] = go[col * LS + h];
+    if (pow2) fft_pass<true, NT>(fb, tw, p.logH, H, p.logH, CB, g.logCB, 1, LS, tid);
+    else { dft_lines<true, NT>(fb, b, tw, H, CB, 1, LS, tid); go = b; }
+    for (int id = tid; id < CB * H; id += NT) {
+        const int h = id >> g.logCB, col = id & (CB - 1), kx = kx0 + col;
+        if (kx < g.WH) wss[(size_t)h * g.WH + kx] = go[col * LS + h];
     }
     for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
     if ((tid & 63) == 0) red[tid >> 6] = lsum;
     __syncthreads();
     if (tid == 0) {
         float s = 0.f;
-        for (int q = 0; q < FFT_THREADS / 64; ++q) s += red[q];
+        for (int q = 0; q < NT / 64; ++q) s += red[q];
         p.partials[(size_t)(g.plane0 + pl) * g.col_groups + cg] = s * p.inv_n0;
     }
 }
@@ -354,9 +408,9 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_rows_inv_kernel(const FftPara
     fill_twiddles(tw, W, pow2 ? (W >> 1) : W, tid);
     const float2* wss = (const float2*)p.ws + (size_t)pl * 2 * g.WH * H + (size_t)g.WH * H;
     for (int id = tid; id < R * W; id += FFT_THREADS) {
-        const int r = id & (R - 1), kx = id >> g.logR, h = h0 + r;
+        const int r = id / W, kx = id - r * W, h = h0 + r;
         float2 v = make_float2(0.f, 0.f);
-        if (kx < g.WH && h < H) v = wss[(size_t)kx * H + h];
+        if (kx < g.WH && h < H) v = wss[(size_t)h * g.WH + kx];
         z[r * LS + (pow2 ? brev_n(kx, p.logW) : kx)] = v;
     }
     __syncthreads();
@@ -367,6 +421,41 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_rows_inv_kernel(const FftPara
     for (int id = tid; id < R * W; id += FFT_THREADS) {
         const int r = id / W, w = id - r * W, h = h0 + r;
         if (h < H) p.gS[(base + (size_t)h * W + w) * p.s_cs + c] += zo[r * LS + w].x;
+    }
+}
+
+// pass C, band-grouped (power-of-two W).  grid = npatches * groups * row_tiles
+template <int BG>
+__global__ __launch_bounds__(FFT_ROWS_THREADS) void fft_rows_inv_grouped_kernel(const FftParams p, const FftBigGeom g)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    constexpr int Q = BG / 4, NT = FFT_ROWS_THREADS;
+    const int tid = threadIdx.x, H = p.H, W = p.W, LS = W + 1, R = g.R;
+    const int per = g.groups * g.row_tiles;
+    const int pn = blockIdx.x / per, rem = blockIdx.x - pn * per, cg = rem / g.row_tiles, rt = rem - cg * g.row_tiles;
+    const int n = g.patch0 + pn, c0 = cg * BG, h0 = rt * R;
+    float2* z = (float2*)smem_f;
+    float2* tw = z + BG * R * LS;
+    fill_twiddles<NT>(tw, W, W >> 1, tid);
+    const size_t pf = (size_t)2 * g.WH * H;
+    for (int id = tid; id < BG * R * W; id += NT) {
+        const int line = id >> p.logW, kx = id & (W - 1), b = line >> g.logR, r = line & (R - 1), h = h0 + r;
+        float2 v = make_float2(0.f, 0.f);
+        if (kx < g.WH && h < H && c0 + b < p.B)
+            v = ((const float2*)p.ws + ((size_t)pn * p.B + c0 + b) * pf + (size_t)g.WH * H)[(size_t)h * g.WH + kx];
+        z[line * LS + brev_n(kx, p.logW)] = v;
+    }
+    __syncthreads();
+    fft_pass<true, NT>(z, tw, p.logW, W, p.logW, BG * R, g.logBG + g.logR, 1, LS, tid);
+    const size_t base = (size_t)n * H * W;
+    for (int id = tid; id < R * W * Q; id += NT) {
+        const int q = id % Q, px = id / Q, r = px >> p.logW, w = px & (W - 1), h = h0 + r, c = c0 + 4 * q;
+        if (h >= H || c >= p.s_cs || c >= p.B) continue;
+        float* gp = p.gS + (base + (size_t)h * W + w) * p.s_cs + c;
+        f32x4 gv = *(const f32x4*)gp;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (c + j < p.B) gv[j] += z[((4 * q + j) * R + r) * LS + w].x;
+        *(f32x4*)gp = gv;
     }
 }
 
@@ -385,9 +474,24 @@ int ssie_fft_supported(int H, int W)
     return (H <= 4096 && W <= 4096) ? 3 : 0;
 }
 
+int ssie_fft_grouped = 1;             // include/ssie_debug.h: 0 = planes that fit the LDS always run the whole-plane kernel
+extern "C" void ssie_debug_set_fft_grouped(int v) { ssie_fft_grouped = v; }
+static bool grouped_geom(int N, int B, int H, int W, int* BGo, int* Ro);
+
+// the path a (N, B, H, W) problem takes: ssie_fft_supported's answer, except that planes which would fit the LDS go through the
+// three-pass path with band-grouped rows when that applies (power-of-two W, at least 64 x 64 - smaller planes are launch-bound
+// either way - and a whole patch per workspace chunk)
+int ssie_fft_path(int N, int B, int H, int W)
+{
+    const int kind = ssie_fft_supported(H, W);
+    if ((kind == 1 || kind == 2) && ssie_fft_grouped && (long)H * W >= 4096 && grouped_geom(N, B, H, W, nullptr, nullptr)) return 3;
+    return kind;
+}
+
 void ssie_fft_set_logs(FftParams& p)
 {
-    const int kind = ssie_fft_supported(p.H, p.W);
+    const int kind = ssie_fft_path(p.N, p.B, p.H, p.W);
+    p.path = kind;
     if (kind == 1) { p.logH = ilog2(p.H); p.logW = ilog2(p.W); }
     else if (kind == 3) { p.logH = is_pow2(p.H) ? ilog2(p.H) : -1; p.logW = is_pow2(p.W) ? ilog2(p.W) : -1; }   // per axis
     else { p.logH = -1; p.logW = -1; }
@@ -412,25 +516,39 @@ int big_chunk_planes(int N, int B, int H, int W)
 // number of loss partial sums the Fourier kernels write (and the finalize kernel reads)
 int ssie_fft_partials(int N, int B, int H, int W)
 {
-    if (ssie_fft_supported(H, W) == 3) return N * B * ssie_ceil_div(W / 2 + 1, big_CB(H));
+    if (ssie_fft_path(N, B, H, W) == 3) return N * B * ssie_ceil_div(W / 2 + 1, big_CB(H));
     return ssie_fft_grid(N, B);
 }
 
 size_t ssie_fft_workspace_floats(int N, int B, int H, int W)
 {
-    if (ssie_fft_supported(H, W) != 3) return 0;
+    if (ssie_fft_path(N, B, H, W) != 3) return 0;
     return (size_t)big_chunk_planes(N, B, H, W) * big_plane_floats(H, W);
+}
+
+// band-grouped passes A / C: BG = 16 bands (8 / 4 for narrow cubes) x R rows per workgroup within a 66 KB LDS budget (two
+// workgroups per CU); needs a power-of-two W and a workspace chunk that holds all B planes of at least one patch
+static bool grouped_geom(int N, int B, int H, int W, int* BGo, int* Ro)
+{
+    if (!is_pow2(W) || B < 2) return false;
+    if (big_chunk_planes(N, B, H, W) < B) return false;
+    const int BG = B > 8 ? 16 : B > 4 ? 8 : 4;
+    int R = 16;
+    while (R > 1 && ((size_t)BG * R * (W + 1) * 8 > 66 * 1024 || R > H)) R >>= 1;
+    if ((size_t)BG * R * (W + 1) * 8 + (size_t)(W / 2) * 8 + 64 > 150 * 1024) return false;
+    if (BGo) *BGo = BG; if (Ro) *Ro = R;
+    return true;
 }
 
 static void allow_big_lds(const void* fn)
 {
-    static bool done[64] = {false};               // per (device, kernel): hipFuncSetAttribute is per device
-    static const void* fns[4] = {nullptr, nullptr, nullptr, nullptr};
+    static bool done[16 * 12] = {false};          // per (device, kernel): hipFuncSetAttribute is per device
+    static const void* fns[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int dev = 0; hipGetDevice(&dev);
-    int slot = 0; for (; slot < 4 && fns[slot] && fns[slot] != fn; ++slot) {}
-    if (slot == 4 || dev < 0 || dev >= 16) { hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return; }
+    int slot = 0; for (; slot < 12 && fns[slot] && fns[slot] != fn; ++slot) {}
+    if (slot == 12 || dev < 0 || dev >= 16) { hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return; }
     fns[slot] = fn;
-    if (!done[dev * 4 + slot]) { hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done[dev * 4 + slot] = true; }
+    if (!done[dev * 12 + slot]) { hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done[dev * 12 + slot] = true; }
 }
 
 static int launch_fft_big(const FftParams& p, hipStream_t st)
@@ -442,13 +560,36 @@ static int launch_fft_big(const FftParams& p, hipStream_t st)
     const bool p2w = p.logW >= 0, p2h = p.logH >= 0;
     const size_t ldsA = (size_t)g.R * (p.W + 1) * 8 * (p2w ? 1 : 2) + (size_t)(p2w ? p.W / 2 : p.W) * 8 + 64;
     const size_t ldsB = (size_t)g.CB * (p.H + 1) * 8 * (p2h ? 2 : 4) + (size_t)(p2h ? p.H / 2 : p.H) * 8 + 64 + FFT_THREADS / 64 * 4;
+    const dim3 colsT(FFT_COLS_THREADS);
     if (ldsA > 160 * 1024 || ldsB > 160 * 1024) return 54;
     allow_big_lds((const void*)fft_rows_fwd_kernel); allow_big_lds((const void*)fft_cols_kernel); allow_big_lds((const void*)fft_rows_inv_kernel);
     const int total = p.N * p.B, chunk = big_chunk_planes(p.N, p.B, p.H, p.W);
+    int BG = 0, Rg = 0;
+    // (float4 accesses along the band axis: 16-byte aligned tensors with channel strides that are multiples of 4; anything else
+    // takes the one-plane-per-workgroup passes below - same workspace, same partial sums)
+    const bool al4 = p.x_cs % 4 == 0 && p.s_cs % 4 == 0 && (((uintptr_t)p.x | (uintptr_t)p.S | (uintptr_t)p.gS) & 15) == 0;
+    if (ssie_fft_grouped && p2w && al4 && grouped_geom(p.N, p.B, p.H, p.W, &BG, &Rg)) {
+        // band-grouped rows: chunks of whole patches
+        g.BG = BG; g.logBG = ilog2(BG); g.groups = ssie_ceil_div(p.B, BG);
+        g.R = Rg; g.logR = ilog2(Rg); g.row_tiles = ssie_ceil_div(p.H, Rg);
+        const size_t ldsG = (size_t)BG * Rg * (p.W + 1) * 8 + (size_t)(p.W / 2) * 8 + 64;
+        const int pchunk = chunk / p.B;
+#define FG_LAUNCH(K, BGV) do { allow_big_lds((const void*)K<BGV>);                                                          \
+        hipLaunchKernelGGL(K<BGV>, dim3(g.npatches * g.groups * g.row_tiles), dim3(FFT_ROWS_THREADS), ldsG, st, p, g); } while (0)
+        for (int n0 = 0; n0 < p.N; n0 += pchunk) {
+            g.patch0 = n0; g.npatches = p.N - n0 < pchunk ? p.N - n0 : pchunk;
+            g.plane0 = n0 * p.B; g.nplanes = g.npatches * p.B;
+            if (BG == 16) FG_LAUNCH(fft_rows_fwd_grouped_kernel, 16); else if (BG == 8) FG_LAUNCH(fft_rows_fwd_grouped_kernel, 8); else FG_LAUNCH(fft_rows_fwd_grouped_kernel, 4);
+            hipLaunchKernelGGL(fft_cols_kernel, dim3(g.nplanes * g.col_groups), colsT, ldsB, st, p, g);
+            if (BG == 16) FG_LAUNCH(fft_rows_inv_grouped_kernel, 16); else if (BG == 8) FG_LAUNCH(fft_rows_inv_grouped_kernel, 8); else FG_LAUNCH(fft_rows_inv_grouped_kernel, 4);
+        }
+#undef FG_LAUNCH
+        return hipGetLastError() == hipSuccess ? 0 : 55;
+    }
     for (int p0 = 0; p0 < total; p0 += chunk) {
         g.plane0 = p0; g.nplanes = total - p0 < chunk ? total - p0 : chunk;
         hipLaunchKernelGGL(fft_rows_fwd_kernel, dim3(g.nplanes * g.row_tiles), dim3(FFT_THREADS), ldsA, st, p, g);
-        hipLaunchKernelGGL(fft_cols_kernel, dim3(g.nplanes * g.col_groups), dim3(FFT_THREADS), ldsB, st, p, g);
+        hipLaunchKernelGGL(fft_cols_kernel, dim3(g.nplanes * g.col_groups), colsT, ldsB, st, p, g);
         hipLaunchKernelGGL(fft_rows_inv_kernel, dim3(g.nplanes * g.row_tiles), dim3(FFT_THREADS), ldsA, st, p, g);
     }
     return hipGetLastError() == hipSuccess ? 0 : 55;
@@ -456,14 +597,15 @@ static int launch_fft_big(const FftParams& p, hipStream_t st)
 
 int ssie_launch_fft_loss(const FftParams& p, hipStream_t st)
 {
-    const int kind = ssie_fft_supported(p.H, p.W);
-    if (!kind) return 51;
+    const int kind = p.path;                           // decided by ssie_fft_set_logs (the workspace and partial-sum sizes follow it)
+    if (!kind || !ssie_fft_supported(p.H, p.W)) return 51;
     if (kind == 3) return launch_fft_big(p, st);
     if ((kind == 1) != (p.logH >= 0)) return 51;
     const int M = p.H > p.W ? p.H : p.W;
     size_t lds = (size_t)p.H * (p.W + 1) * 8 + (kind == 1 ? (size_t)(M / 2) * 8 : (size_t)(p.H + p.W) * 8) + 64;
+    const int vblocks = ssie_fft_grid(p.N, p.B);
     allow_big_lds((const void*)fft_loss_kernel);
-    hipLaunchKernelGGL(fft_loss_kernel, dim3(ssie_fft_grid(p.N, p.B)), dim3(FFT_THREADS), lds, st, p);
+    hipLaunchKernelGGL(fft_loss_kernel, dim3(vblocks), dim3(FFT_THREADS), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : 52;
 }
 

@@ -29,6 +29,7 @@ struct FftParams {
     float inv_n0;
     float* partials;                 // [ssie_fft_partials(N, B, H, W)]
     float* ws;                       // three-pass path only: ssie_fft_workspace_floats(N, B, H, W) floats
+    int path;                        // ssie_fft_path(N, B, H, W) at the time ssie_fft_set_logs ran: 1 / 2 whole plane in LDS, 3 three passes
 };
 
 int ssie_launch_loss_direct(const LossParams& p, int nblk, hipStream_t st);
@@ -47,6 +48,7 @@ int ssie_launch_upsample_adjoint(const float* src, int Hv, int Wv, int src_cs, f
 int ssie_launch_adam(float* p, const float* g, float* m, float* v, long n, float gscale, float lr, int step,
                      float b1, float b2, float eps, hipStream_t st);
 int ssie_fft_supported(int H, int W);
+int ssie_fft_path(int N, int B, int H, int W);      // the path taken: as ssie_fft_supported, or 3 where the band-grouped three-pass path applies
 int ssie_fft_grid(int N, int B);
 int ssie_fft_partials(int N, int B, int H, int W);
 size_t ssie_fft_workspace_floats(int N, int B, int H, int W);

@@ -153,6 +153,14 @@ __global__ __launch_bounds__(256) void loss_direct_kernel(const LossParams p)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
 
+// The tiled kernels are VALU-bound at wide band counts (PMC at 256 bands: ~300 vector instructions per band and pixel, VALU busy
+// 45 % of the kernel, HBM 1.3 TB/s), so their two hot primitives are the short forms:
+//   sg(v)   = copysign(v != 0, v): compare + select + bit-field insert (exact; the generic kernel's (v > 0) - (v < 0) is five)
+//   exp(-t) = v_exp_f32(-t * log2 e): two instructions, relative error ~4e-7 at t = 10 (expf: ~15 instructions, 1e-7); the
+//             results only weight magnitudes (never decide a sign) and are held to 1e-5 of the tensor maximum by the tests
+__device__ __forceinline__ float sg3(float v) { return __builtin_copysignf(v != 0.f ? 1.f : 0.f, v); }
+__device__ __forceinline__ float expneg(float t) { return __builtin_amdgcn_exp2f(t * -1.44269504088896341f); }
+
 template <int LPP>
 __device__ __forceinline__ float grp_sum(float v)      // sum over the LPP lanes that share a pixel
 {
@@ -247,7 +255,7 @@ __global__ __launch_bounds__(256) void loss_tile_kernel(const LossParams p, int 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float d = sgnd[k] * (rn[j] - r0[j]);                 // one subtraction, like the reference's R[1:] - R[:-1]
-                    const float ex = expf(-p.a2 * fabsf(d));
+                    const float ex = expneg(p.a2 * fabsf(d));
                     dRv[k][j] = d; exv[k][j] = ex;
                     ddv[k][j] = sgnd[k] * ((rn[j] - en[j]) - (r0[j] - e0[j]));
                     as += cm[j] * fabsf(d); es += cm[j] * ex;
@@ -260,22 +268,22 @@ __global__ __launch_bounds__(256) void loss_tile_kernel(const LossParams p, int 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float t = r0[j] * I0 - xr[j];
-                srec[j] = cm[j] * sgnf(t);
+                srec[j] = cm[j] * sg3(t);
                 srs += srec[j] * r0[j];
                 acc_rec += live ? cm[j] * fabsf(t) * p.inv_n0 : 0.f;
             }
             srs = grp_sum<LPP>(srs);
             float wgt[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) wgt[k] = expf(-p.a1 * a_sum[k] * invC);
+            for (int k = 0; k < 4; ++k) wgt[k] = expneg(p.a1 * a_sum[k] * invC);
             // ---- per-pixel cotangents (I_low, I_delta): identical on all LPP lanes; the lane owning channel B stores gI ----
             float gI = p.c_rec * p.inv_n0 * srs, gDv = 0.f;
             {
                 const float nIx = p.inv_nIx, nIy = p.inv_nIy, nRx = p.inv_nRx, nRy = p.inv_nRy;
-                gI += -fR * p.c_il * wgt[0] * sgnf(u[0]) * nIx + fL * p.c_il * wgt[1] * sgnf(u[1]) * nIx
-                      - fD * p.c_il * wgt[2] * sgnf(u[2]) * nIy + fU * p.c_il * wgt[3] * sgnf(u[3]) * nIy;
-                gDv += -fR * p.c_id * sgnf(v[0]) * e_sum[0] * nRx + fL * p.c_id * sgnf(v[1]) * e_sum[1] * nRx
-                       - fD * p.c_id * sgnf(v[2]) * e_sum[2] * nRy + fU * p.c_id * sgnf(v[3]) * e_sum[3] * nRy;
+                gI += -fR * p.c_il * wgt[0] * sg3(u[0]) * nIx + fL * p.c_il * wgt[1] * sg3(u[1]) * nIx
+                      - fD * p.c_il * wgt[2] * sg3(u[2]) * nIy + fU * p.c_il * wgt[3] * sg3(u[3]) * nIy;
+                gDv += -fR * p.c_id * sg3(v[0]) * e_sum[0] * nRx + fL * p.c_id * sg3(v[1]) * e_sum[1] * nRx
+                       - fD * p.c_id * sg3(v[2]) * e_sum[2] * nRy + fU * p.c_id * sg3(v[3]) * e_sum[3] * nRy;
                 if (sub == 0) acc_il += fR * wgt[0] * fabsf(u[0]) * nIx + fD * wgt[2] * fabsf(u[2]) * nIy;
             }
             // ---- per-band cotangents ----
@@ -291,13 +299,13 @@ __global__ __launch_bounds__(256) void loss_tile_kernel(const LossParams p, int 
                 const int c = c0 + j;
                 const float d0 = r0[j] - e0[j];
                 float g = p.c_rec * p.inv_n0 * srec[j] * I0;
-                float gdel = sgnf(d0) * p.inv_n0;
+                float gdel = sg3(d0) * p.inv_n0;
                 acc_rf += live ? cm[j] * fabsf(d0) * p.inv_n0 : 0.f;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float d = dRv[k][j], ex = exv[k][j], dd = ddv[k][j];
-                    g += esg[k] * hasf[k] * sgnf(d) * (kil[k] * wgt[k] * fabsf(u[k]) + kid[k] * fabsf(v[k]) * ex);
-                    gdel -= esg[k] * hasf[k] * 0.5f * sgnf(dd) * nR[k];
+                    g += esg[k] * hasf[k] * sg3(d) * (kil[k] * wgt[k] * fabsf(u[k]) + kid[k] * fabsf(v[k]) * ex);
+                    gdel -= esg[k] * hasf[k] * 0.5f * sg3(dd) * nR[k];
                     if (k == 0 || k == 2) {                                  // each edge's loss is counted at its left / upper end
                         acc_rf += cm[j] * hasf[k] * 0.5f * fabsf(dd) * nR[k];
                         acc_id += cm[j] * hasf[k] * fabsf(v[k]) * ex * nR[k];
@@ -311,8 +319,8 @@ __global__ __launch_bounds__(256) void loss_tile_kernel(const LossParams p, int 
                 const float s0 = sr[j];
                 const float sm = j > 0 ? sr[j - 1] : s_prev, sp = j < 3 ? sr[j + 1] : s_next;
                 float gsv = 0.f;
-                if (c > 0 && c < B) gsv += sgnf(s0 - sm);
-                if (c + 1 < B) { const float t = sp - s0; gsv -= sgnf(t); acc_sp += live ? fabsf(t) * p.inv_nsp : 0.f; }
+                if (c > 0 && c < B) gsv += sg3(s0 - sm);
+                if (c + 1 < B) { const float t = sp - s0; gsv -= sg3(t); acc_sp += live ? fabsf(t) * p.inv_nsp : 0.f; }
                 gs[j] = p.c_sp * p.inv_nsp * gsv;
             }
             if (live) {
@@ -320,6 +328,267 @@ __global__ __launch_bounds__(256) void loss_tile_kernel(const LossParams p, int 
                 if (lane_rl) { *(f32x4*)(p.gRL + pix * p.rl_cs + c0) = gR; *(f32x4*)(p.G8b + pix * p.e_cs + c0) = g8; }
                 if (lane_x) *(f32x4*)(p.gS + pix * p.s_cs + c0) = gs;
                 if (sub == 0) p.gD[pix * p.d_cs] = gDv;
+            }
+        }
+    }
+    // block reduction of the five loss sums (every block writes its slot, also when it had no tile)
+    __shared__ float red[5][4];
+    float s5[5] = {acc_rec, acc_rf, acc_il, acc_id, acc_sp};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { float t = s5[k]; for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o); s5[k] = t; }
+    __syncthreads();
+    if ((tid & 63) == 0) for (int k = 0; k < 5; ++k) red[k][tid >> 6] = s5[k];
+    __syncthreads();
+    if (tid < 5) p.partials[(size_t)blockIdx.x * 8 + tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Band-chunked variant of the tiled kernel, for band counts whose pixel vector does not fit one pass of the kernel above (more
+// than 252 bands: BASELINE configs[2] has 256) or whose tile would leave one workgroup per CU.  A pixel's band vector is walked
+// in chunks of CB = 4 * LPP bands; a tile stages only the chunk it is working on (R|I and R_enh with the one-pixel halo), so the
+// LDS footprint is that of a CB-band problem (2 - 3 workgroups per CU: one workgroup's staging runs under another's arithmetic).
+// Two sweeps over the chunks:
+//   sweep 1 (R only)  a_k = sum_c |dR_c| per edge -> the edge weights w_k = exp(-a1 mean_c |dR|), the only quantities a per-band
+//                     cotangent needs from OTHER bands
+//   sweep 2           everything per band (cotangents of R, R_enh, S; loss sums), and the remaining band sums (sum_c exp(-a2
+//                     |dR_c|) per edge, sum_c sg(R I - x) R), which only feed the per-PIXEL cotangents of I_low / I_delta that are
+//                     stored after the sweep.  R is read twice (the second time from L2).
+// Per element the arithmetic is that of loss_tile_kernel (single subtractions for every sg() argument).
+// ---------------------------------------------------------------------------------------------
+template <int LPP>
+__global__ __launch_bounds__(256) void loss_chunk_kernel(const LossParams p, int TH, int TW, int tiles_y, int tiles_x)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_l[];
+    constexpr int SLOTS = 256 / LPP;                   // pixels per pass
+    constexpr int MAXPASS = 4;
+    constexpr int CB = 4 * LPP;                        // bands per chunk
+    const int B = p.B, H = p.H, W = p.W;
+    const int PW = TW + 2, PH = TH + 2, pxh = PH * PW;
+    float* RLt = smem_l;                               // [PH][PW][CB]
+    float* Et = RLt + (size_t)pxh * CB;                // [PH][PW][CB]
+    float* It = Et + (size_t)pxh * CB;                 // [PH][PW]  I_low
+    float* Dt = It + pxh;                              // [PH][PW]  I_delta
+    const int tid = threadIdx.x, sub = tid % LPP, grp = tid / LPP;
+    const int nchunk = (B + CB - 1) / CB;
+    const int nq = p.rl_cs >> 2;                       // float4s per pixel of RL / E (x / S: the same count or one less, never read past B)
+    const float invC = 1.f / (float)B;
+    const float kil_x = p.c_il * p.a1 * invC * p.inv_nIx, kil_y = p.c_il * p.a1 * invC * p.inv_nIy;
+    const float kid_x = p.c_id * p.a2 * p.inv_nRx, kid_y = p.c_id * p.a2 * p.inv_nRy;
+    float acc_rec = 0.f, acc_rf = 0.f, acc_il = 0.f, acc_id = 0.f, acc_sp = 0.f;
+    const int per_img = tiles_y * tiles_x, ntiles = p.N * per_img, npass = (TH * TW + SLOTS - 1) / SLOTS;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const float sgnd[4] = {1.f, -1.f, 1.f, -1.f};      // edge difference = sgnd * (neighbour - own), edges R, L, D, U
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int n = tile / per_img, tr = tile - n * per_img, ty = tr / tiles_x, tx = tr - ty * tiles_x;
+        const int h0 = ty * TH, w0 = tx * TW;
+        const long img = (long)n * H * W;
+        // per-pass pixel of this lane group
+        int li[MAXPASS]; bool live[MAXPASS]; float hasf[MAXPASS][4];
+#pragma unroll
+        for (int ps = 0; ps < MAXPASS; ++ps) {
+            const int idx = ps * SLOTS + grp, ph = idx / TW, pw = idx - ph * TW, h = h0 + ph, w = w0 + pw;
+            live[ps] = ps < npass && idx < TH * TW && h < H && w < W;
+            li[ps] = live[ps] ? (ph + 1) * PW + (pw + 1) : PW + 1;       // dead slots read a valid LDS address and store nothing
+            hasf[ps][0] = (live[ps] && w + 1 < W) ? 1.f : 0.f; hasf[ps][1] = (live[ps] && w > 0) ? 1.f : 0.f;
+            hasf[ps][2] = (live[ps] && h + 1 < H) ? 1.f : 0.f; hasf[ps][3] = (live[ps] && h > 0) ? 1.f : 0.f;
+        }
+        __syncthreads();                               // the previous tile's LDS reads are done
+        for (int i = tid; i < pxh; i += 256) {
+            const int py = i / PW, pxx = i - py * PW, hh = h0 - 1 + py, ww = w0 - 1 + pxx;
+            const bool in = hh >= 0 && hh < H && ww >= 0 && ww < W;
+            const long pix = img + (long)hh * W + ww;
+            It[i] = in ? p.RL[pix * p.rl_cs + B] : 0.f;
+            Dt[i] = in ? p.D[pix * p.d_cs] : 0.f;
+        }
+        // ---- sweep 1: sum_c |dR_c| per edge ----
+        float asum[MAXPASS][4];
+#pragma unroll
+        for (int ps = 0; ps < MAXPASS; ++ps)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) asum[ps][k] = 0.f;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            if (ch) __syncthreads();                   // the previous chunk's LDS reads are done
+            for (int i = tid; i < pxh * LPP; i += 256) {
+                const int px = i / LPP, q = i - px * LPP, py = px / PW, pxx = px - py * PW;
+                const int hh = h0 - 1 + py, ww = w0 - 1 + pxx, cq = ch * LPP + q;
+                f32x4 a = z4;
+                if (hh >= 0 && hh < H && ww >= 0 && ww < W && cq < nq) a = ld4(p.RL + (img + (long)hh * W + ww) * p.rl_cs + 4 * cq);
+                *(f32x4*)(RLt + (size_t)px * CB + 4 * q) = a;
+            }
+            __syncthreads();
+            const int c0 = ch * CB + sub * 4;
+            float cm[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cm[j] = (c0 + j < B) ? 1.f : 0.f;
+#pragma unroll
+            for (int ps = 0; ps < MAXPASS; ++ps) {
+                if (ps >= npass) break;
+                const f32x4 r0 = *(const f32x4*)(RLt + (size_t)li[ps] * CB + sub * 4);
+                const int nb[4] = {li[ps] + 1, li[ps] - 1, li[ps] + PW, li[ps] - PW};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 rn = *(const f32x4*)(RLt + (size_t)nb[k] * CB + sub * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) asum[ps][k] += cm[j] * fabsf(sgnd[k] * (rn[j] - r0[j]));
+                }
+            }
+        }
+        float wgt[MAXPASS][4];
+#pragma unroll
+        for (int ps = 0; ps < MAXPASS; ++ps)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wgt[ps][k] = expneg(p.a1 * (grp_sum<LPP>(asum[ps][k]) * hasf[ps][k]) * invC);
+
+        // ---- sweep 2: per-band cotangents, loss sums, and the band sums of the per-pixel cotangents ----
+        float esum[MAXPASS][4], srs[MAXPASS];
+#pragma unroll
+        for (int ps = 0; ps < MAXPASS; ++ps) { srs[ps] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) esum[ps][k] = 0.f; }
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int c0 = ch * CB + sub * 4;
+            const bool lane_c = c0 < B;                // this lane's float4 holds at least one real band
+            // x and S of this lane's pixels straight to registers, issued before the staging loads
+            f32x4 xv[MAXPASS], sv[MAXPASS];
+#pragma unroll
+            for (int ps = 0; ps < MAXPASS; ++ps) {
+                const int idx = ps * SLOTS + grp, ph = idx / TW, pw = idx - ph * TW;
+                const long pix = img + (long)(h0 + ph) * W + (w0 + pw);
+                const bool ok = live[ps] && lane_c;
+                xv[ps] = ok ? ld4(p.x + pix * p.x_cs + c0) : z4;
+                sv[ps] = ok ? ld4(p.S + pix * p.s_cs + c0) : z4;
+            }
+            __syncthreads();                           // sweep 1's / the previous chunk's LDS reads are done
+            for (int i = tid; i < pxh * LPP; i += 256) {
+                const int px = i / LPP, q = i - px * LPP, py = px / PW, pxx = px - py * PW;
+                const int hh = h0 - 1 + py, ww = w0 - 1 + pxx, cq = ch * LPP + q;
+                f32x4 a = z4, b = z4;
+                if (hh >= 0 && hh < H && ww >= 0 && ww < W && cq < nq) {
+                    const long pix = img + (long)hh * W + ww;
+                    a = ld4(p.RL + pix * p.rl_cs + 4 * cq); b = ld4(p.E + pix * p.e_cs + 4 * cq);
+                }
+                *(f32x4*)(RLt + (size_t)px * CB + 4 * q) = a;
+                *(f32x4*)(Et + (size_t)px * CB + 4 * q) = b;
+            }
+            __syncthreads();
+            float cm[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cm[j] = (c0 + j < B) ? 1.f : 0.f;
+#pragma unroll
+            for (int ps = 0; ps < MAXPASS; ++ps) {
+                if (ps >= npass) break;
+                const int l0 = li[ps];
+                const int nb[4] = {l0 + 1, l0 - 1, l0 + PW, l0 - PW};
+                const f32x4 r0 = *(const f32x4*)(RLt + (size_t)l0 * CB + sub * 4);
+                const f32x4 e0 = *(const f32x4*)(Et + (size_t)l0 * CB + sub * 4);
+                const float I0 = It[l0], D0 = Dt[l0];
+                float u[4], v[4];
+                f32x4 dRv[4], exv[4], ddv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 rn = *(const f32x4*)(RLt + (size_t)nb[k] * CB + sub * 4);
+                    const f32x4 en = *(const f32x4*)(Et + (size_t)nb[k] * CB + sub * 4);
+                    u[k] = sgnd[k] * (It[nb[k]] - I0);
+                    v[k] = sgnd[k] * (Dt[nb[k]] - D0);
+                    float es = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float d = sgnd[k] * (rn[j] - r0[j]);
+                        const float ex = expneg(p.a2 * fabsf(d));
+                        dRv[k][j] = d; exv[k][j] = ex;
+                        ddv[k][j] = sgnd[k] * ((rn[j] - en[j]) - (r0[j] - e0[j]));
+                        es += cm[j] * ex;
+                    }
+                    esum[ps][k] += es;
+                }
+                const f32x4 xr = xv[ps];
+                float srec[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float t = r0[j] * I0 - xr[j];
+                    srec[j] = cm[j] * sg3(t);
+                    srs[ps] += srec[j] * r0[j];
+                    acc_rec += live[ps] ? cm[j] * fabsf(t) * p.inv_n0 : 0.f;
+                }
+                const float kil[4] = {kil_x, kil_x, kil_y, kil_y}, kid[4] = {kid_x, kid_x, kid_y, kid_y};
+                const float nR[4] = {p.inv_nRx, p.inv_nRx, p.inv_nRy, p.inv_nRy};
+                const float esg[4] = {1.f, -1.f, 1.f, -1.f};                    // own-end sign of an edge's flux
+                f32x4 gR, g8, gs;
+                const f32x4 sr = sv[ps];
+                const int idx = ps * SLOTS + grp, ph = idx / TW, pw = idx - ph * TW;
+                const long pix = img + (long)(h0 + ph) * W + (w0 + pw);
+                // band neighbours of S across the float4 boundary: adjacent lanes of the pixel group; across a CHUNK boundary the
+                // neighbouring band is read from memory (one L1-resident float)
+                float s_prev = __shfl_up(sr[3], 1), s_next = __shfl_down(sr[0], 1);
+                if (live[ps] && lane_c) {
+                    if (sub == 0 && c0 > 0) s_prev = p.S[pix * p.s_cs + c0 - 1];
+                    if (sub == LPP - 1 && c0 + 4 < B) s_next = p.S[pix * p.s_cs + c0 + 4];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = c0 + j;
+                    const float d0 = r0[j] - e0[j];
+                    float g = p.c_rec * p.inv_n0 * srec[j] * I0;
+                    float gdel = sg3(d0) * p.inv_n0;
+                    acc_rf += live[ps] ? cm[j] * fabsf(d0) * p.inv_n0 : 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float d = dRv[k][j], ex = exv[k][j], dd = ddv[k][j], hf = hasf[ps][k];
+                        g += esg[k] * hf * sg3(d) * (kil[k] * wgt[ps][k] * fabsf(u[k]) + kid[k] * fabsf(v[k]) * ex);
+                        gdel -= esg[k] * hf * 0.5f * sg3(dd) * nR[k];
+                        if (k == 0 || k == 2) {                                  // each edge's loss is counted at its left / upper end
+                            acc_rf += cm[j] * hf * 0.5f * fabsf(dd) * nR[k];
+                            acc_id += cm[j] * hf * fabsf(v[k]) * ex * nR[k];
+                        }
+                    }
+                    g += p.c_rf * gdel;
+                    const float ge = p.ge_raw ? -p.c_rf * gdel : -p.c_rf * gdel * e0[j] * (1.f - e0[j]);
+                    gR[j] = c < B ? g : 0.f;           // channel B (I_low) and the padding channels: stored after the sweep / zero
+                    g8[j] = c < B ? ge : 0.f;
+                    const float s0 = sr[j];
+                    const float sm = j > 0 ? sr[j - 1] : s_prev, sp = j < 3 ? sr[j + 1] : s_next;
+                    float gsv = 0.f;
+                    if (c > 0 && c < B) gsv += sg3(s0 - sm);
+                    if (c + 1 < B) { const float t = sp - s0; gsv -= sg3(t); acc_sp += live[ps] ? fabsf(t) * p.inv_nsp : 0.f; }
+                    gs[j] = p.c_sp * p.inv_nsp * gsv;
+                }
+                if (live[ps] && lane_c) {
+                    *(f32x4*)(p.gRL + pix * p.rl_cs + c0) = gR; *(f32x4*)(p.G8b + pix * p.e_cs + c0) = g8;
+                    *(f32x4*)(p.gS + pix * p.s_cs + c0) = gs;
+                }
+            }
+        }
+        // ---- per-pixel cotangents (I_low, I_delta), after the last chunk ----
+#pragma unroll
+        for (int ps = 0; ps < MAXPASS; ++ps) {
+            if (ps >= npass) break;
+            const int l0 = li[ps];
+            const int nb[4] = {l0 + 1, l0 - 1, l0 + PW, l0 - PW};
+            const float I0 = It[l0], D0 = Dt[l0];
+            float u[4], v[4], es[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                u[k] = sgnd[k] * (It[nb[k]] - I0); v[k] = sgnd[k] * (Dt[nb[k]] - D0);
+                es[k] = grp_sum<LPP>(esum[ps][k]) * hasf[ps][k];
+            }
+            const float srsum = grp_sum<LPP>(srs[ps]);
+            const float fR = hasf[ps][0], fL = hasf[ps][1], fD = hasf[ps][2], fU = hasf[ps][3];
+            const float nIx = p.inv_nIx, nIy = p.inv_nIy, nRx = p.inv_nRx, nRy = p.inv_nRy;
+            float gI = p.c_rec * p.inv_n0 * srsum, gDv = 0.f;
+            gI += -fR * p.c_il * wgt[ps][0] * sg3(u[0]) * nIx + fL * p.c_il * wgt[ps][1] * sg3(u[1]) * nIx
+                  - fD * p.c_il * wgt[ps][2] * sg3(u[2]) * nIy + fU * p.c_il * wgt[ps][3] * sg3(u[3]) * nIy;
+            gDv += -fR * p.c_id * sg3(v[0]) * es[0] * nRx + fL * p.c_id * sg3(v[1]) * es[1] * nRx
+                   - fD * p.c_id * sg3(v[2]) * es[2] * nRy + fU * p.c_id * sg3(v[3]) * es[3] * nRy;
+            if (live[ps] && sub == 0) {
+                acc_il += fR * wgt[ps][0] * fabsf(u[0]) * nIx + fD * wgt[ps][2] * fabsf(u[2]) * nIy;
+                const int idx = ps * SLOTS + grp, ph = idx / TW, pw = idx - ph * TW;
+                const long pix = img + (long)(h0 + ph) * W + (w0 + pw);
+                p.gD[pix * p.d_cs] = gDv;
+                if ((B & 3) == 0) {                    // I_low opens a float4 of its own: [gI, 0, 0, 0] (and zeros in G8b: I_enh is unused, model.py:546)
+                    *(f32x4*)(p.gRL + pix * p.rl_cs + B) = f32x4{gI, 0.f, 0.f, 0.f};
+                    *(f32x4*)(p.G8b + pix * p.e_cs + B) = z4;
+                } else p.gRL[pix * p.rl_cs + B] = gI;  // inside the last band float4, which the sweep stored with a 0 here (same wave, program order)
             }
         }
     }
@@ -489,13 +758,26 @@ static void allow_lds(const void* fn, size_t bytes)
 
 int ssie_loss_force_generic = 0;      // include/ssie_debug.h: 1 = always the half-wave-per-pixel kernel (tests run both)
 
+int ssie_loss_chunked = 0;            // include/ssie_debug.h: 1 = the band-chunked tiled kernel also where the one-pass tiled kernel applies
+
 int ssie_launch_loss_direct(const LossParams& p, int nblk, hipStream_t st)
 {
     const int nq = p.rl_cs / 4;
     const bool aligned = (((uintptr_t)p.x | (uintptr_t)p.RL | (uintptr_t)p.S | (uintptr_t)p.E | (uintptr_t)p.gRL | (uintptr_t)p.gS |
                            (uintptr_t)p.G8b) & 15) == 0;
-    const bool tiled = !ssie_loss_force_generic && aligned && p.rl_cs == p.e_cs && p.x_cs == p.s_cs && p.rl_cs % 4 == 0 &&
-                       p.x_cs % 4 == 0 && p.x_cs <= p.rl_cs && p.B < p.rl_cs && nq <= 64;
+    const bool layout = aligned && p.rl_cs == p.e_cs && p.x_cs == p.s_cs && p.rl_cs % 4 == 0 && p.x_cs % 4 == 0 && p.x_cs <= p.rl_cs &&
+                        p.B < p.rl_cs;
+    const bool tiled = !ssie_loss_force_generic && layout && nq <= 64;
+    // more than 252 bands (or on request): chunks of 64 bands, 4 x 16 pixel tiles (54 KB of LDS: two to three workgroups per CU)
+    const bool chunked = !ssie_loss_force_generic && layout && p.x_cs >= ssie_round_up(p.B, 4) && (nq > 64 || ssie_loss_chunked);
+    if (chunked) {
+        const int TW = 16, TH = 4;
+        const int tiles_y = ssie_ceil_div(p.H, TH), tiles_x = ssie_ceil_div(p.W, TW);
+        const size_t lds = (size_t)(TH + 2) * (TW + 2) * (2 * 64 + 2) * 4;
+        allow_lds((const void*)loss_chunk_kernel<16>, lds);
+        hipLaunchKernelGGL(loss_chunk_kernel<16>, dim3(nblk), dim3(256), lds, st, p, TH, TW, tiles_y, tiles_x);
+        return hipGetLastError() == hipSuccess ? 0 : 41;
+    }
     if (!tiled) {
         hipLaunchKernelGGL(loss_direct_kernel, dim3(nblk), dim3(256), 0, st, p);
         return hipGetLastError() == hipSuccess ? 0 : 41;

@@ -28,6 +28,8 @@ Layout layout(int N, int B, int H, int W)
 
 extern int ssie_loss_force_generic;
 extern "C" void ssie_debug_set_loss_generic(int v) { ssie_loss_force_generic = v; }
+extern int ssie_loss_chunked;
+extern "C" void ssie_debug_set_loss_chunked(int v) { ssie_loss_chunked = v; }
 
 extern "C" size_t ssie_selfsup_loss_workspace_bytes(int N, int bands, int H, int W)
 {

@@ -183,7 +183,7 @@ void build_buffers(Plan& pl)
     pl.lpart_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + (size_t)pl.loss_blocks * 8, 64);
     pl.fpart_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + (size_t)pl.fft_blocks, 64);
     pl.scal_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 16, 64);
-    pl.fftws_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + ssie_fft_workspace_floats(N, B, H, W), 64);   // patches above 128 x 128 only
+    pl.fftws_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + ssie_fft_workspace_floats(N, B, H, W), 64);   // three-pass Fourier loss (band-grouped rows, or planes larger than the LDS)
     pl.mask_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + ((size_t)H * W + 3) / 4, 64);
     pl.tailw_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 3 * 9 * 64 + 16, 64);     // composite weights of the fused tail
     {   // spectral 9 x 9: X^ of both passes [f][2 Mt][Kp], Y^ / halo-G^ [f][Mt][64], Z^ [f][Mt][Kp], no-halo G^ [f][2 Mt][64], weights, dW^ slices

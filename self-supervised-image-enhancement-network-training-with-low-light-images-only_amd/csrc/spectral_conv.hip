@@ -68,6 +68,12 @@ __device__ __forceinline__ void fft32(float2 (&v)[32])
 
 constexpr int CG = 8;                              // channels per workgroup of the tile transforms
 constexpr int RS = T + 1;                          // padded row stride of the real tile in LDS
+// per-channel plane strides.  The spectral <-> global copies run lanes over the 8 channels first (a 64-byte segment of
+// X^[f][m][c]): with the natural strides (544 complex = 1088 dwords, 1056 floats) all channels of a bin fall on ONE bank - PMC:
+// SQ_LDS_BANK_CONFLICT was half of SQ_LDS_IDX_ACTIVE in both transform kernels.  +4 complex puts the 8 channels 8 banks apart
+// (with 4 bins x 2 banks in between: conflict-free); +4 floats puts the two channel quads of the real-tile copies 16 banks apart.
+constexpr int PS = T * KX + 4;                     // complex elements per channel plane of Cx
+constexpr int RP = T * RS + 4;                     // floats per channel plane of R
 
 // ---- x -> X^ ------------------------------------------------------------------------------------------------------------
 // grid (Cp / 8, tiles of this tensor); window origin = (V*a + org, V*b + org); `valid` = 32 for halo windows (org = -4),
@@ -77,10 +83,10 @@ __global__ __launch_bounds__(256) void spec_fft_tiles_kernel(const float* __rest
 {
     // the real tile R and the half-complex tile Cx share one buffer (static LDS is limited to 64 KB): a row is pulled into
     // registers, and only after a barrier written back as its spectrum
-    __shared__ float2 buf[CG * T * KX];
-    float* R = (float*)buf;                        // [CG][T][RS] floats  (33.8 KB of the 34.8 KB)
-    float2* Cx = buf;                              // [CG][T][KX] complex
-    static_assert(CG * T * RS * 4 <= CG * T * KX * 8, "R must fit inside Cx");
+    __shared__ float2 buf[CG * PS];
+    float* R = (float*)buf;                        // [CG][RP] floats: rows of RS  (33.9 KB of the 35.1 KB)
+    float2* Cx = buf;                              // [CG][PS] complex: rows of KX
+    static_assert(CG * RP * 4 <= CG * PS * 8, "R must fit inside Cx");
     // workgroup id -> (tile, channel group), XCD-aware: consecutive ids go round-robin over the 8 XCDs (each with its own L2), so
     // the channel groups of ONE tile - which share its 128-byte cache lines - take ids 8 apart: same XCD, back to back in time
     const int tid = threadIdx.x;
@@ -95,34 +101,34 @@ __global__ __launch_bounds__(256) void spec_fft_tiles_kernel(const float* __rest
         if (y < valid && x < valid && gy >= 0 && gy < H && gx >= 0 && gx < W && c0 + 4 * q < cs)
             v = *(const f32x4*)(in + (((size_t)n * H + gy) * W + gx) * cs + c0 + 4 * q);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) R[((4 * q + j) * T + y) * RS + x] = v[j];
+        for (int j = 0; j < 4; ++j) R[(4 * q + j) * RP + y * RS + x] = v[j];
     }
     __syncthreads();
     {   // rows: one real row of 32 per thread
         const int c = tid >> 5, y = tid & 31;
         float2 v[32];
 #pragma unroll
-        for (int x = 0; x < 32; ++x) v[x] = make_float2(R[(c * T + y) * RS + x], 0.f);
+        for (int x = 0; x < 32; ++x) v[x] = make_float2(R[c * RP + y * RS + x], 0.f);
         fft32<false>(v);
         __syncthreads();                           // every row of R is in registers: the buffer may now hold spectra
 #pragma unroll
-        for (int kx = 0; kx < KX; ++kx) Cx[(c * T + y) * KX + kx] = v[kx];
+        for (int kx = 0; kx < KX; ++kx) Cx[c * PS + y * KX + kx] = v[kx];
     }
     __syncthreads();
     if (tid < CG * KX) {   // columns: one complex column of 32 per thread, in place
         const int c = tid / KX, kx = tid % KX;
         float2 v[32];
 #pragma unroll
-        for (int y = 0; y < 32; ++y) v[y] = Cx[(c * T + y) * KX + kx];
+        for (int y = 0; y < 32; ++y) v[y] = Cx[c * PS + y * KX + kx];
         fft32<false>(v);
 #pragma unroll
-        for (int ky = 0; ky < 32; ++ky) Cx[(c * T + ky) * KX + kx] = v[ky];
+        for (int ky = 0; ky < 32; ++ky) Cx[c * PS + ky * KX + kx] = v[ky];
     }
     __syncthreads();
     const size_t m = (size_t)m0 + mloc;
     for (int idx = tid; idx < NF * CG; idx += 256) {
         const int c = idx & (CG - 1), f = idx >> 3;
-        out[((size_t)f * Mtot + m) * Cp + c0 + c] = Cx[(c * T + f / KX) * KX + f % KX];
+        out[((size_t)f * Mtot + m) * Cp + c0 + c] = Cx[c * PS + f];     // f = ky * KX + kx is the in-plane offset
     }
 }
 
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(256) void spec_fft_tiles_kernel(const float* __rest
 __global__ __launch_bounds__(256) void spec_ifft_out_kernel(const float2* __restrict__ Yf, int m0, int Mtot, int Np, int H, int W, int tiles_y, int tiles_x,
                                                             float* __restrict__ out, int cs, int Cout, const float* __restrict__ bias, int accumulate, int ntiles, int ncg)
 {
-    __shared__ float2 buf[CG * T * KX];            // Cx, then (after a barrier) the real tile R: see spec_fft_tiles_kernel
+    __shared__ float2 buf[CG * PS];                // Cx, then (after a barrier) the real tile R: see spec_fft_tiles_kernel
     float* R = (float*)buf;
     float2* Cx = buf;
     const int tid = threadIdx.x;           // (tile, channel group) from the workgroup id as in spec_fft_tiles_kernel
@@ -141,31 +147,31 @@ __global__ __launch_bounds__(256) void spec_ifft_out_kernel(const float2* __rest
     const size_t m = (size_t)m0 + mloc;
     for (int idx = tid; idx < NF * CG; idx += 256) {
         const int c = idx & (CG - 1), f = idx >> 3;
-        Cx[(c * T + f / KX) * KX + f % KX] = (c0 + c < Np) ? Yf[((size_t)f * Mtot + m) * Np + c0 + c] : make_float2(0.f, 0.f);
+        Cx[c * PS + f] = (c0 + c < Np) ? Yf[((size_t)f * Mtot + m) * Np + c0 + c] : make_float2(0.f, 0.f);
     }
     __syncthreads();
     if (tid < CG * KX) {
         const int c = tid / KX, kx = tid % KX;
         float2 v[32];
 #pragma unroll
-        for (int ky = 0; ky < 32; ++ky) v[ky] = Cx[(c * T + ky) * KX + kx];
+        for (int ky = 0; ky < 32; ++ky) v[ky] = Cx[c * PS + ky * KX + kx];
         fft32<true>(v);
 #pragma unroll
-        for (int y = 0; y < 32; ++y) Cx[(c * T + y) * KX + kx] = v[y];
+        for (int y = 0; y < 32; ++y) Cx[c * PS + y * KX + kx] = v[y];
     }
     __syncthreads();
     {   // rows: Hermitian half spectrum -> 32 reals (only the 24 valid rows / columns are kept)
         const int c = tid >> 5, y = tid & 31;
         float2 v[32];
 #pragma unroll
-        for (int kx = 0; kx < KX; ++kx) v[kx] = Cx[(c * T + y) * KX + kx];
+        for (int kx = 0; kx < KX; ++kx) v[kx] = Cx[c * PS + y * KX + kx];
         __syncthreads();                           // all spectra are in registers: the buffer may now hold the real tile
         if (y < V) {
 #pragma unroll
             for (int kx = KX; kx < 32; ++kx) v[kx] = make_float2(v[32 - kx].x, -v[32 - kx].y);
             fft32<true>(v);
 #pragma unroll
-            for (int x = 0; x < V; ++x) R[(c * T + y) * RS + x] = v[x].x * (1.f / (T * T));
+            for (int x = 0; x < V; ++x) R[c * RP + y * RS + x] = v[x].x * (1.f / (T * T));
         }
     }
     __syncthreads();
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(256) void spec_ifft_out_kernel(const float2* __rest
         float* o = out + (((size_t)n * H + gy) * W + gx) * cs + c;
         f32x4 v;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (c + j < Cout) ? R[((4 * q + j) * T + y) * RS + x] + (bias ? bias[c + j] : 0.f) : 0.f;
+        for (int j = 0; j < 4; ++j) v[j] = (c + j < Cout) ? R[(4 * q + j) * RP + y * RS + x] + (bias ? bias[c + j] : 0.f) : 0.f;
         if (accumulate) { const f32x4 old = *(const f32x4*)o; v += old; }
         *(f32x4*)o = v;
     }

@@ -28,7 +28,10 @@ for _k in ("c_rec", "c_rf", "c_il", "c_id", "c_sp"):
 GEOMS = {"b5_16": (1, 5, 16, 16), "b31_32": (2, 31, 32, 32), "b31_64": (2, 31, 64, 64), "b8_24x40": (2, 8, 24, 40),
          "b31_128": (1, 31, 128, 128), "b40_48": (1, 40, 48, 48),       # 40 bands: 16 lanes per pixel in the tiled kernel
          "b64_24x40": (1, 64, 24, 40), "b130_16x24": (1, 130, 16, 24),   # 32 and 64 lanes per pixel (shipped configs use 64 bands)
-         "b12_20x36": (2, 12, 20, 36)}                                   # B % 4 == 0: I_low sits in a float4 of its own
+         "b12_20x36": (2, 12, 20, 36),                                   # B % 4 == 0: I_low sits in a float4 of its own
+         # more than 252 bands: the band-chunked tiled kernel (loss_chunk_kernel) is the default path.  256 = BASELINE configs[2]
+         # (I_low in a float4 of its own, four full 64-band chunks), 258: I_low inside the last band float4, ragged last chunk
+         "b256_16x24": (1, 256, 16, 24), "b258_12x20": (1, 258, 12, 20)}
 
 
 @pytest.fixture(scope="module")
@@ -40,13 +43,16 @@ def H():
     return hostlib
 
 
-@pytest.fixture(params=["tiled", "half_wave"])
+@pytest.fixture(params=["tiled", "half_wave", "chunked"])
 def loss_kernel(H, request):
-    """both loss kernels through every case: the LDS-tiled one the plan runs, and the half-wave-per-pixel one it falls back
-    to for layouts the tiled kernel does not take (include/ssie_debug.h)"""
+    """all three loss kernels through every case: the LDS-tiled one the plan runs up to 252 bands, the band-chunked tiled one it
+    runs above that (forced here for every band count), and the half-wave-per-pixel one for layouts neither takes
+    (include/ssie_debug.h)"""
     H.lib().ssie_debug_set_loss_generic(1 if request.param == "half_wave" else 0)
+    H.lib().ssie_debug_set_loss_chunked(1 if request.param == "chunked" else 0)
     yield request.param
     H.lib().ssie_debug_set_loss_generic(0)
+    H.lib().ssie_debug_set_loss_chunked(0)
 
 
 _cache = {}
@@ -123,14 +129,32 @@ def test_spatial_terms_elementwise(H, geom, coefset, loss_kernel):
                                        ((g - r).abs() * (~amb[key])).max().item() / scale)
 
 
-@pytest.mark.parametrize("geom", ["b5_16", "b31_32", "b31_64", "b8_24x40", "b31_128", "b5_256", "b4_160x288"])
-def test_fourier_term_per_bin(H, geom):
+@pytest.fixture(params=["grouped", "whole_plane"])
+def fft_kernel(H, request):
+    """planes of 64 x 64 and more with a power-of-two width take the three-pass path with band-grouped rows
+    (fft_rows_*_grouped_kernel) by default; the second value keeps the whole-plane-in-LDS kernel covered on them (smaller planes
+    and the planes that exceed the LDS run the same kernels either way)"""
+    H.lib().ssie_debug_set_fft_grouped(1 if request.param == "grouped" else 0)
+    yield request.param
+    H.lib().ssie_debug_set_fft_grouped(1)
+
+
+@pytest.mark.parametrize("geom", ["b5_16", "b31_32", "b31_64", "b8_24x40", "b31_128", "b5_256", "b4_160x288", "b31_128_n10", "b6_64x128", "b3_256x64"])
+def test_fourier_term_per_bin(H, geom, fft_kernel):
     """only c_f non-zero: gS = c_f Re(HW ifft2(M g_Z));  fft2(gS)/ (HW) = Hermitian part of c_f M g_Z, compared bin by bin.
     b5_256 / b4_160x288 take the three-pass path for planes larger than the LDS (model.py:456-473 accepts any patch size)."""
+    if fft_kernel != "grouped" and geom not in ("b31_64", "b31_128"):
+        pytest.skip("same kernel as the first parameter value")
     if geom == "b5_256":
         n, b, h, w = 1, 5, 256, 256
+    elif geom == "b31_128_n10":                        # 10 patches of 31 bands (groups of 16 + 15)
+        n, b, h, w = 10, 31, 128, 128
     elif geom == "b4_160x288":
         n, b, h, w = 2, 4, 160, 288
+    elif geom == "b6_64x128":                          # band groups of 8; H != W
+        n, b, h, w = 3, 6, 64, 128
+    elif geom == "b3_256x64":                          # band groups of 4 (one float4 holds all bands + padding); 256 rows
+        n, b, h, w = 2, 3, 256, 64
     else:
         n, b, h, w = GEOMS[geom]
     if geom in GEOMS:

@@ -3,8 +3,14 @@ import csv, glob, os, re, sys
 from collections import defaultdict
 
 def short(name):
-    name = re.sub(r"^void ", "", name)
-    return re.sub(r"\(.*$", "", name).strip()
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
+    depth = 0
+    for i, ch in enumerate(name):
+        if ch == "<": depth += 1
+        elif ch == ">": depth -= 1
+        elif ch == "(" and depth == 0:
+            return name[:i].strip()
+    return name.strip()
 
 dirs = [a for a in sys.argv[1:] if not a.startswith("--")]
 flt = None
@@ -16,7 +22,7 @@ for d in dirs:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
-            if flt and flt not in k:
+            if flt and not re.search(flt, k):
                 continue
             a = acc[k][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
 for k, cs in sorted(acc.items()):
