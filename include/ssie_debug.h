@@ -36,13 +36,14 @@ void ssie_debug_set_fprop_v2_split(int on);             /* [1] 0 = one 8-wave wo
 void ssie_debug_set_fprop_v2_split_min_tiles(int v);    /* [1024] */
 void ssie_debug_set_fprop_wgs_per_cu(int v);
 void ssie_debug_set_tconv(int v);                       /* [1] 0 = stride-2 transposed 3x3 convolutions always as four output-parity launches (plans created afterwards) */
-void ssie_debug_set_tconv_min_tiles(int v);             /* [256] fewest 16x16 input tiles for the one-launch kernel */
+void ssie_debug_set_tconv_min_tiles(int v);             /* [32] fewest 16x16 input tiles for the one-launch kernel */
 void ssie_debug_set_fft_grouped(int v);                 /* [1] 0 = Fourier loss planes that fit the LDS always run the whole-plane kernel (fft_loss_kernel); plans / operator calls made afterwards */
+void ssie_debug_set_loss_chunk_lpp(int v);              /* [8] lanes per pixel of loss_chunk_kernel: 8 = 32-band chunks on 8x16 tiles, 16 = 64-band chunks on 4x16 tiles */
 void ssie_debug_set_loss_chunked(int v);                /* [0] 1 = the band-chunked tiled loss kernel (loss_chunk_kernel, normally only above 252 bands) for every band count */
 void ssie_debug_set_wino(int v);                        /* [1] 0 = stride-1 3x3 launches never run the Winograd F(2x2,3x3) kernel (plans created afterwards) */
 void ssie_debug_set_wino_min_tiles(int v);
 void ssie_debug_set_wgrad_wino(int v);                  /* [1] 0 = stride-1 3x3 weight gradients never run the Winograd F(3x3,2x2) kernel (plans created afterwards) */
-void ssie_debug_set_wgrad_wino_min_tiles(int v);        /* [256] fewest 8x16 position tiles for which it is chosen */              /* [256] fewest 16x32x32-channel tiles for which it is chosen */
+void ssie_debug_set_wgrad_wino_min_tiles(int v);        /* [32] fewest 8x16 position tiles for which it is chosen */              /* [256] fewest 16x32x32-channel tiles for which it is chosen */
 void ssie_debug_set_fused_tail(int on);                 /* [1] 0 = inference keeps feature_fusion / final_conv / compose as separate launches (plans bound afterwards) */
 void ssie_debug_set_spectral9(int on);                  /* [1] 0 = the 9 x 9 convolution (shallow_conv) on the direct MFMA kernels instead of the frequency domain (plans created afterwards) */
 void ssie_debug_set_skinny_final(int on);               /* [1] 0 = final_conv (64 -> 1) forward / gradients on the MFMA tile kernels (plans created afterwards) */

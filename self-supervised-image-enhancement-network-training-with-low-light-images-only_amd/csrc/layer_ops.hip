@@ -60,7 +60,8 @@ TapList ssie_taps_transposed_all(void)
 
 // ---- one-launch transposed convolution (conv_tconv.hip) ----
 int ssie_fprop_tconv = 1;              // A/B switch: 1 = eligible stride-2 transposed 3x3 convolutions run conv_tconv_kernel
-int ssie_fprop_tconv_min_tiles = 256;  // ... when the input has at least this many 16 x 16 tiles (tests set 1)
+int ssie_fprop_tconv_min_tiles = 32;   // ... when the input has at least this many 16 x 16 tiles (tests set 1): below 256 tiles the four
+                                       // parity-class launches are launch-latency-bound (4 x ~20 us at the 16 x 16 / 32 x 32 pyramid levels)
 extern "C" void ssie_debug_set_tconv(int v) { ssie_fprop_tconv = v; }
 extern "C" void ssie_debug_set_tconv_min_tiles(int v) { ssie_fprop_tconv_min_tiles = v; }
 

@@ -169,6 +169,14 @@ __device__ __forceinline__ float grp_sum(float v)      // sum over the LPP lanes
     return v;
 }
 
+// tile geometry of the tiled kernels: four passes of 256 / LPP pixels, 16 (LPP <= 16) or 8 pixels wide
+template <int LPP> struct LossTile {
+    static constexpr int SLOTS = 256 / LPP, TW = LPP <= 16 ? 16 : 8, TH = 4 * SLOTS / TW, PW = TW + 2, PH = TH + 2, PXH = PH * PW;
+    static constexpr int NIT = (PXH * LPP + 255) / 256;           // staging iterations per thread (LPP 16-byte slots per halo pixel)
+};
+
+// (tile size as RUN-TIME arguments and a run-time staging loop: with compile-time geometry, or with the staging loads batched as in
+// loss_chunk_kernel below, hipcc allocates 256 instead of 227 registers and the kernel runs 0.26 - 0.29 instead of 0.19 ms at 31 bands)
 template <int LPP>
 __global__ __launch_bounds__(256) void loss_tile_kernel(const LossParams p, int TH, int TW, int tiles_y, int tiles_x)
 {
@@ -356,14 +364,14 @@ __global__ __launch_bounds__(256) void loss_tile_kernel(const LossParams p, int 
 // Per element the arithmetic is that of loss_tile_kernel (single subtractions for every sg() argument).
 // ---------------------------------------------------------------------------------------------
 template <int LPP>
-__global__ __launch_bounds__(256) void loss_chunk_kernel(const LossParams p, int TH, int TW, int tiles_y, int tiles_x)
+__global__ __launch_bounds__(256) void loss_chunk_kernel(const LossParams p, int tiles_y, int tiles_x)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_l[];
     constexpr int SLOTS = 256 / LPP;                   // pixels per pass
     constexpr int MAXPASS = 4;
     constexpr int CB = 4 * LPP;                        // bands per chunk
+    constexpr int TW = LossTile<LPP>::TW, TH = LossTile<LPP>::TH, PW = TW + 2, PH = TH + 2, pxh = PH * PW, NIT = LossTile<LPP>::NIT;
     const int B = p.B, H = p.H, W = p.W;
-    const int PW = TW + 2, PH = TH + 2, pxh = PH * PW;
     float* RLt = smem_l;                               // [PH][PW][CB]
     float* Et = RLt + (size_t)pxh * CB;                // [PH][PW][CB]
     float* It = Et + (size_t)pxh * CB;                 // [PH][PW]  I_low
@@ -409,12 +417,20 @@ __global__ __launch_bounds__(256) void loss_chunk_kernel(const LossParams p, int
             for (int k = 0; k < 4; ++k) asum[ps][k] = 0.f;
         for (int ch = 0; ch < nchunk; ++ch) {
             if (ch) __syncthreads();                   // the previous chunk's LDS reads are done
-            for (int i = tid; i < pxh * LPP; i += 256) {
-                const int px = i / LPP, q = i - px * LPP, py = px / PW, pxx = px - py * PW;
-                const int hh = h0 - 1 + py, ww = w0 - 1 + pxx, cq = ch * LPP + q;
-                f32x4 a = z4;
-                if (hh >= 0 && hh < H && ww >= 0 && ww < W && cq < nq) a = ld4(p.RL + (img + (long)hh * W + ww) * p.rl_cs + 4 * cq);
-                *(f32x4*)(RLt + (size_t)px * CB + 4 * q) = a;
+            {   // all of a thread's staging loads in flight together (see loss_tile_kernel)
+                f32x4 av[NIT];
+#pragma unroll
+                for (int u = 0; u < NIT; ++u) {
+                    const int i = tid + u * 256, px = i / LPP, q = i % LPP, py = px / PW, pxx = px - py * PW;
+                    const int hh = h0 - 1 + py, ww = w0 - 1 + pxx, cq = ch * LPP + q;
+                    av[u] = z4;
+                    if (px < pxh && hh >= 0 && hh < H && ww >= 0 && ww < W && cq < nq) av[u] = ld4(p.RL + (img + (long)hh * W + ww) * p.rl_cs + 4 * cq);
+                }
+#pragma unroll
+                for (int u = 0; u < NIT; ++u) {
+                    const int i = tid + u * 256, px = i / LPP, q = i % LPP;
+                    if (px < pxh) *(f32x4*)(RLt + (size_t)px * CB + 4 * q) = av[u];
+                }
             }
             __syncthreads();
             const int c0 = ch * CB + sub * 4;
@@ -460,16 +476,27 @@ __global__ __launch_bounds__(256) void loss_chunk_kernel(const LossParams p, int
                 sv[ps] = ok ? ld4(p.S + pix * p.s_cs + c0) : z4;
             }
             __syncthreads();                           // sweep 1's / the previous chunk's LDS reads are done
-            for (int i = tid; i < pxh * LPP; i += 256) {
-                const int px = i / LPP, q = i - px * LPP, py = px / PW, pxx = px - py * PW;
-                const int hh = h0 - 1 + py, ww = w0 - 1 + pxx, cq = ch * LPP + q;
-                f32x4 a = z4, b = z4;
-                if (hh >= 0 && hh < H && ww >= 0 && ww < W && cq < nq) {
-                    const long pix = img + (long)hh * W + ww;
-                    a = ld4(p.RL + pix * p.rl_cs + 4 * cq); b = ld4(p.E + pix * p.e_cs + 4 * cq);
+#pragma unroll
+            for (int b0 = 0; b0 < NIT; b0 += 4) {      // batches of four slots per thread (eight loads in flight)
+                f32x4 av[4], bv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = tid + (b0 + u) * 256, px = i / LPP, q = i % LPP, py = px / PW, pxx = px - py * PW;
+                    const int hh = h0 - 1 + py, ww = w0 - 1 + pxx, cq = ch * LPP + q;
+                    av[u] = z4; bv[u] = z4;
+                    if (b0 + u < NIT && px < pxh && hh >= 0 && hh < H && ww >= 0 && ww < W && cq < nq) {
+                        const long pix = img + (long)hh * W + ww;
+                        av[u] = ld4(p.RL + pix * p.rl_cs + 4 * cq); bv[u] = ld4(p.E + pix * p.e_cs + 4 * cq);
+                    }
                 }
-                *(f32x4*)(RLt + (size_t)px * CB + 4 * q) = a;
-                *(f32x4*)(Et + (size_t)px * CB + 4 * q) = b;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = tid + (b0 + u) * 256, px = i / LPP, q = i % LPP;
+                    if (b0 + u < NIT && px < pxh) {
+                        *(f32x4*)(RLt + (size_t)px * CB + 4 * q) = av[u];
+                        *(f32x4*)(Et + (size_t)px * CB + 4 * q) = bv[u];
+                    }
+                }
             }
             __syncthreads();
             float cm[4];
@@ -758,6 +785,8 @@ static void allow_lds(const void* fn, size_t bytes)
 
 int ssie_loss_force_generic = 0;      // include/ssie_debug.h: 1 = always the half-wave-per-pixel kernel (tests run both)
 
+int ssie_loss_chunk_lpp = 8;          // dev switch (tools): lanes per pixel of the band-chunked kernel, 8 (32-band chunks) or 16 (64-band chunks)
+extern "C" void ssie_debug_set_loss_chunk_lpp(int v) { ssie_loss_chunk_lpp = v; }
 int ssie_loss_chunked = 0;            // include/ssie_debug.h: 1 = the band-chunked tiled kernel also where the one-pass tiled kernel applies
 
 int ssie_launch_loss_direct(const LossParams& p, int nblk, hipStream_t st)
@@ -771,11 +800,13 @@ int ssie_launch_loss_direct(const LossParams& p, int nblk, hipStream_t st)
     // more than 252 bands (or on request): chunks of 64 bands, 4 x 16 pixel tiles (54 KB of LDS: two to three workgroups per CU)
     const bool chunked = !ssie_loss_force_generic && layout && p.x_cs >= ssie_round_up(p.B, 4) && (nq > 64 || ssie_loss_chunked);
     if (chunked) {
-        const int TW = 16, TH = 4;
+        // chunks of 32 bands on 8 x 16 pixel tiles (47 KB of LDS: three workgroups per CU, halo 1.4x) or of 64 bands on 4 x 16 tiles
+        const int lpp = ssie_loss_chunk_lpp == 16 ? 16 : 8;
+        const int TW = 16, TH = lpp == 8 ? LossTile<8>::TH : LossTile<16>::TH;
         const int tiles_y = ssie_ceil_div(p.H, TH), tiles_x = ssie_ceil_div(p.W, TW);
-        const size_t lds = (size_t)(TH + 2) * (TW + 2) * (2 * 64 + 2) * 4;
-        allow_lds((const void*)loss_chunk_kernel<16>, lds);
-        hipLaunchKernelGGL(loss_chunk_kernel<16>, dim3(nblk), dim3(256), lds, st, p, TH, TW, tiles_y, tiles_x);
+        const size_t lds = (size_t)(TH + 2) * (TW + 2) * (2 * 4 * lpp + 2) * 4;
+        if (lpp == 8) { allow_lds((const void*)loss_chunk_kernel<8>, lds); hipLaunchKernelGGL(loss_chunk_kernel<8>, dim3(nblk), dim3(256), lds, st, p, tiles_y, tiles_x); }
+        else { allow_lds((const void*)loss_chunk_kernel<16>, lds); hipLaunchKernelGGL(loss_chunk_kernel<16>, dim3(nblk), dim3(256), lds, st, p, tiles_y, tiles_x); }
         return hipGetLastError() == hipSuccess ? 0 : 41;
     }
     if (!tiled) {
@@ -783,7 +814,7 @@ int ssie_launch_loss_direct(const LossParams& p, int nblk, hipStream_t st)
         return hipGetLastError() == hipSuccess ? 0 : 41;
     }
     const int lpp = nq <= 8 ? 8 : nq <= 16 ? 16 : nq <= 32 ? 32 : 64;
-    const int TW = lpp <= 16 ? 16 : 8, TH = 4 * (256 / lpp) / TW;          // 4 passes of 256 / LPP pixels
+    const int TW = lpp <= 16 ? 16 : 8, TH = 4 * (256 / lpp) / TW;          // 4 passes of 256 / LPP pixels (= LossTile<lpp>)
     const int tiles_y = ssie_ceil_div(p.H, TH), tiles_x = ssie_ceil_div(p.W, TW);
     const size_t lds = (size_t)(TH + 2) * (TW + 2) * (2 * p.rl_cs + 1) * 4;
 #define LAUNCH_TILE(L) do { allow_lds((const void*)loss_tile_kernel<L>, lds);                                               \

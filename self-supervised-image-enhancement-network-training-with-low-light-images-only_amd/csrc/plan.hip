@@ -165,7 +165,7 @@ void build_buffers(Plan& pl)
     alloc(pl, "lse", N, 4, H8 * W8, 1); alloc(pl, "delta", N, 4, H8 * W8, 1);
     alloc(pl, "u1", N, H4, W4, 64); alloc(pl, "d1", N, H4, W4, 64); alloc(pl, "u2", N, H2, W2, 64); alloc(pl, "d2", N, H2, W2, 64);
     alloc(pl, "u3", N, H, W, 64); alloc(pl, "d3", N, H, W, 64); alloc(pl, "f", N, H, W, 64);
-    alloc(pl, "Gf", N, H, W, 64); alloc(pl, "gd3", N, H, W, 64); alloc(pl, "Ge3", N, H, W, 64); alloc(pl, "tmpH", N, H, W, 64);
+    alloc(pl, "Gf", N, H, W, 64); alloc(pl, "Gf2", N, H2, W2, 64); alloc(pl, "Gf4", N, H4, W4, 64); alloc(pl, "gd3", N, H, W, 64); alloc(pl, "Ge3", N, H, W, 64); alloc(pl, "tmpH", N, H, W, 64);
     alloc(pl, "gd2", N, H2, W2, 64); alloc(pl, "Ge2", N, H2, W2, 64); alloc(pl, "gd1", N, H4, W4, 64); alloc(pl, "Ge1", N, H4, W4, 64);
     alloc(pl, "gt3", N, H8, W8, 64); alloc(pl, "gf1", N, H8, W8, 64); alloc(pl, "gao", N, H8, W8, 64); alloc(pl, "gqkv", N, H8, W8, 192);
     // bf16 inference path: bf16 copies of the tensors that also exist in fp32 (allocated in float units: C/2)
@@ -659,12 +659,18 @@ int build_illum_bwd(Builder& b, std::vector<Fn>& ops)
         ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_skinny_wgrad(fp, gD, 4, part, dw, db, N, H, W, st); }, K_ELEMENTWISE, fl, "final_conv wgrad (VALU)"));
         ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_skinny_dgrad(gD, 4, w, Gf, N, H, W, st); }, K_ELEMENTWISE, fl, "final_conv dgrad (VALU)"));
     }
-    CK(b.wgrad(ops, Lu, 1, b.src("d1", 64, H, W), 64, H, W, 0, "Gf"));
-    CK(b.wgrad(ops, Lu, 1, b.src("d2", 64, H, W), 64, H, W, 64, "Gf"));
+    // feature_fusion is a 1 x 1 convolution over cat[up(d1), up(d2), d3] (model.py:169-173).  A 1 x 1 convolution commutes with
+    // nearest up-sampling, so the gradients of the d1 / d2 parts are taken at THEIR resolution from the up-sampling adjoint of Gf
+    // (Gf2 = U2^T Gf, Gf4 = U4^T Gf):  dW_k = sum_p Gf[p] (x) up(d_k)[p] = sum_q (U^T Gf)[q] (x) d_k[q]  and  gd_k = U^T (W_k^T Gf) =
+    // W_k^T (U^T Gf) - 4x / 16x fewer positions than the full-resolution launches + adjoint of the result (same sums, reassociated).
+    b.upadj(ops, "Gf", H, W, "Gf2", 0);
+    b.upadj(ops, "Gf", H, W, "Gf4", 0);
+    CK(b.wgrad(ops, Lu, 1, b.src("d1", 64, H4, W4), 64, H4, W4, 0, "Gf4"));
+    CK(b.wgrad(ops, Lu, 1, b.src("d2", 64, H2, W2), 64, H2, W2, 64, "Gf2"));
     CK(b.wgrad(ops, Lu, 1, b.src("d3", 64, H, W), 64, H, W, 128, "Gf", 0, true));
     CK(b.dgrad(ops, Lu, 1, "Gf", 0, 128, 64, "gd3", nullptr, 0, 0));
-    CK(b.dgrad(ops, Lu, 1, "Gf", 0, 64, 64, "tmpH", nullptr, 0, 0)); b.upadj(ops, "tmpH", H, W, "gd2", 0);
-    CK(b.dgrad(ops, Lu, 1, "Gf", 0, 0, 64, "tmpH", nullptr, 0, 0)); b.upadj(ops, "tmpH", H, W, "gd1", 0);
+    CK(b.dgrad(ops, Lu, 1, "Gf2", 0, 64, 64, "gd2", nullptr, 0, 0));
+    CK(b.dgrad(ops, Lu, 1, "Gf4", 0, 0, 64, "gd1", nullptr, 0, 0));
     // level H: d3 = relu(e3) + a0
     b.mask_axpy(ops, "gd3", "u3", MASK_RELU, "Ge3", 64, 0);
     CK(b.wgrad(ops, Ld3, 1, b.src("d2", 64, H, W), 64, H, W, 0, "Ge3", 0, true));

@@ -37,7 +37,7 @@ def kernel_mode(H, request):
         L.ssie_debug_set_fprop_wide_min_tiles(1 if request.param == "tile16x32" else 1 << 30)
         L.ssie_debug_set_fprop_v2_split_min_tiles(1 if request.param == "tile16x32" else 1 << 30)   # 32-channel layers: two 4-wave workgroups per CU
     yield request.param
-    L.ssie_debug_set_tconv_min_tiles(256)
+    L.ssie_debug_set_tconv_min_tiles(32)
     L.ssie_debug_set_wino_min_tiles(256)
     L.ssie_debug_set_wgrad_wino_min_tiles(256)
     L.ssie_debug_set_fprop_min_tiles16(256)
