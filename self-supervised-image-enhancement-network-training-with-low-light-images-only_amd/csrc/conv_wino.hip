@@ -187,29 +187,53 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     // DMA of one step's operands: 4 pieces of U and 5 halo slots per lane.  VALU instructions and MFMAs SHARE a SIMD's issue slot on
     // this chip (tools/coexec_bench.hip: every v_add between two MFMAs costs its 4 cycles, with one or two waves per SIMD), so
-    // the per-slot address arithmetic is kept minimal: a per-lane table in LDS holds, for each of the lane's 5 slots,
-    //   halo pixel offset hy*Wv + hx (15 bits) | channel quad j << 15 | hy << 17 | hx << 22      (hy = 31: padding slot)
-    // and a step only adds the scalar tile base and compares hy / hx / j against scalar ranges.  (UP variants: sources of
-    // different sizes: the slot is decoded arithmetically - x / 17 = x * 241 >> 12 for x < 306.)
+    // the per-slot address arithmetic is kept minimal.  The operands are fetched through BUFFER descriptors (buffer_load_dwordx4
+    // ... lds): one scalar resource per (source, image) whose num_records is the image's byte size, so a halo row above or below
+    // the image is an out-of-range offset and the hardware writes zeros - no row compare, no 64-bit address, no zero page.  A
+    // per-lane table in LDS holds, for each of the lane's 5 slots,
+    //   byte offset of the slot relative to the tile origin (24 bits; sources of one channel stride: the offset of halo pixel
+    //   (hy, hx), channel quad j)  |  hx << 24 (6 bits)  |  j << 30          [sources of different strides: pixel offset, not bytes]
+    // and a step adds the scalar tile origin; only tiles that touch the left / right image border or a partial channel chunk
+    // compare hx / j (a column outside the image is a valid address of the neighbouring row).  Padding slots (never read back)
+    // fetch offset 0.  (UP variants: sources of different sizes: every slot is decoded arithmetically - x / 17 = x * 241 >> 12.)
     int* dma_tab = s_next + 4;                      // [W_HPB / NTHR][NTHR]
+    // all sources of this launch share one channel stride (every layer but conv7's c5 | c0 concat): the table holds bytes
+    const int cs_common = SINGLE ? p.src[0].cstride
+                                 : ((p.nsrc < 2 || p.src[1].cstride == p.src[0].cstride) && (p.nsrc < 3 || p.src[2].cstride == p.src[0].cstride)
+                                    ? p.src[0].cstride : 0);
     if (!UP) {
 #pragma unroll
         for (int i = 0; i < W_HPB / NTHR; ++i) {
             const int id = i * NTHR + tid;
             const int j = (id >= W_PLANE) + (id >= 2 * W_PLANE) + (id >= 3 * W_PLANE), r = id - j * W_PLANE;
             const int par = r >= W_HALF, rr = r - par * W_HALF;
-            const int hy = r < 2 * W_HALF ? (rr * 241) >> 12 : 31;
-            const int hx = r < 2 * W_HALF ? 2 * (rr - hy * (W_HPW / 2)) + par : 0;
-            dma_tab[i * NTHR + tid] = (r < 2 * W_HALF ? hy * p.Wv + hx : 0) | (j << 15) | (hy << 17) | (hx << 22);
+            const bool real = r < 2 * W_HALF;
+            const int hy = real ? (rr * 241) >> 12 : 0;
+            const int hx = real ? 2 * (rr - hy * (W_HPW / 2)) + par : 0;
+            const int pix = hy * p.Wv + hx;
+            const int lo = cs_common ? (pix * cs_common + 4 * j) * 4 : pix;
+            dma_tab[i * NTHR + tid] = real ? (lo | (hx << 24) | (j << 30)) : 0;
         }
     }
+    // U pieces: per-lane byte offset inside a piece pair (two (xi, q) rows of 32 float4), constant for the whole kernel
+    const unsigned u_lane = (unsigned)(((lane >> 5) * p.Cout_pad + (lane & 31)) * 16);
+#define WN_RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, (int)(bytes), 0x00020000)
+#define WN_BLDS(rs, lptr, vo, so) __builtin_amdgcn_raw_ptr_buffer_load_lds((rs), (__attribute__((address_space(3))) void*)(lptr), 16, (vo), (so), 0, 0)
 #define WN_PREFETCH(CHUNK, N_, A0_, B0_, CO0_, BUF)                                                           \
     {                                                                                                         \
-        const f32x4* wsrc_ = (const f32x4*)p.wpacked + (size_t)(CHUNK) * 64 * p.Cout_pad + (CO0_);            \
         f32x4* bbuf_ = Bs0 + (BUF) * W_BSZ;                                                                   \
-        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                    \
-            const int pc_ = q_ * 8 + wave;                        /* piece = two (xi, q) rows of 32 float4 */   \
-            GLDS16(wsrc_ + (unsigned)((pc_ * 2 + (lane >> 5)) * p.Cout_pad + (lane & 31)), bbuf_ + pc_ * 64); \
+        if (UP) {                                                                                             \
+            const f32x4* wsrc_ = (const f32x4*)p.wpacked + (size_t)(CHUNK) * 64 * p.Cout_pad + (CO0_);        \
+            _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                \
+                const int pc_ = q_ * 8 + wave;                    /* piece = two (xi, q) rows of 32 float4 */   \
+                GLDS16(wsrc_ + (unsigned)((pc_ * 2 + (lane >> 5)) * p.Cout_pad + (lane & 31)), bbuf_ + pc_ * 64); \
+            }                                                                                                 \
+        } else {                                                                                              \
+            const __amdgpu_buffer_rsrc_t ur_ = WN_RSRC((const f32x4*)p.wpacked + (size_t)(CHUNK) * 64 * p.Cout_pad + (CO0_), 0x7fffffff); \
+            _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                \
+                const int pc_ = q_ * 8 + wave;                                                                \
+                WN_BLDS(ur_, bbuf_ + pc_ * 64, u_lane, (unsigned)(pc_ * 2 * p.Cout_pad * 16));                \
+            }                                                                                                 \
         }                                                                                                     \
         const SrcSel s_ = SINGLE ? ssie_only_src(p) : ssie_pick_src(p, (CHUNK) * SSIE_CK);                    \
         const int vy0_ = (A0_) - 1, vx0_ = (B0_) - 1;                                                         \
@@ -227,21 +251,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }                                                                                                 \
         } else {                                                                                              \
             const int c0_ = (CHUNK) * SSIE_CK - s_.cbeg;                                                      \
-            const int tb_ = (((N_) * p.Hv + vy0_) * p.Wv + vx0_) * s_.cstride + s_.coff + c0_;                \
-            const unsigned ylo_ = max(0, -vy0_), yn_ = min(W_HPH, p.Hv - vy0_) - ylo_;                        \
+            /* one resource per (source, image): rows outside the image are out-of-range offsets -> zeros */  \
+            const __amdgpu_buffer_rsrc_t ar_ = WN_RSRC(s_.ptr + (size_t)(N_) * p.Hv * p.Wv * s_.cstride,       \
+                                                       (unsigned)(p.Hv * p.Wv * s_.cstride) * 4u);            \
+            const int tb_ = ((vy0_ * p.Wv + vx0_) * s_.cstride + s_.coff + c0_) * 4;      /* bytes, may be negative */ \
             const unsigned xlo_ = max(0, -vx0_), xn_ = min(W_HPW, p.Wv - vx0_) - xlo_;                        \
             const int jn_ = (s_.C - c0_ + 3) >> 2;                                                            \
-            const unsigned long long zp_ = (unsigned long long)wino_zero_page;                                \
+            const unsigned cs4_ = (unsigned)s_.cstride * 4u;                                                  \
             /* all table entries first: a DMA writes LDS, so the compiler will not move a table read above the previous DMA */ \
             unsigned te_[W_HPB / NTHR];                                                                       \
             _Pragma("unroll") for (int i_ = 0; i_ < W_HPB / NTHR; ++i_) te_[i_] = (unsigned)dma_tab[i_ * NTHR + tid]; \
-            _Pragma("unroll") for (int i_ = 0; i_ < W_HPB / NTHR; ++i_) {                                     \
-                const unsigned e_ = te_[i_];                                                                  \
-                const unsigned hy_ = (e_ >> 17) & 31, hx_ = e_ >> 22, j_ = (e_ >> 15) & 3;                    \
-                const bool ok_ = hy_ - ylo_ < yn_ && hx_ - xlo_ < xn_ && (int)j_ < jn_;                       \
-                const int off_ = tb_ + (int)(e_ & 0x7fff) * s_.cstride + 4 * (int)j_;                         \
-                const unsigned long long a_ = (unsigned long long)(s_.ptr + off_), m_ = ok_ ? ~0ull : 0ull;    \
-                GLDS16((const f32x4*)((a_ & m_) | (zp_ & ~m_)), abuf_ + i_ * NTHR + wave * 64);               \
+            if (xn_ == (unsigned)W_HPW && jn_ >= 4) {          /* no column outside the image, full channel chunk */ \
+                _Pragma("unroll") for (int i_ = 0; i_ < W_HPB / NTHR; ++i_) {                                 \
+                    const unsigned lo_ = te_[i_] & 0xffffffu;                                                 \
+                    const unsigned off_ = (unsigned)tb_ + (cs_common ? lo_ : __umul24(lo_, cs4_) + ((te_[i_] >> 30) << 4)); \
+                    WN_BLDS(ar_, abuf_ + i_ * NTHR + wave * 64, off_, 0);                                     \
+                }                                                                                             \
+            } else {                                                                                          \
+                _Pragma("unroll") for (int i_ = 0; i_ < W_HPB / NTHR; ++i_) {                                 \
+                    const unsigned e_ = te_[i_], lo_ = e_ & 0xffffffu, hx_ = (e_ >> 24) & 63, j_ = e_ >> 30;  \
+                    const bool ok_ = hx_ - xlo_ < xn_ && (int)j_ < jn_;                                       \
+                    const unsigned off_ = (unsigned)tb_ + (cs_common ? lo_ : __umul24(lo_, cs4_) + (j_ << 4));         \
+                    WN_BLDS(ar_, abuf_ + i_ * NTHR + wave * 64, ok_ ? off_ : 0x80000000u, 0);                 \
+                }                                                                                             \
             }                                                                                                 \
         }                                                                                                     \
     }
@@ -371,6 +403,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     ST_FLUSH;
 #undef WN_PREFETCH
 #undef WN_DECODE
+#undef WN_RSRC
+#undef WN_BLDS
 }
 
 template __global__ void conv_wino_kernel<false, false>(const ConvParams);
@@ -393,8 +427,11 @@ int ssie_launch_fprop_wino(const ConvParams& p, hipStream_t st)
     const size_t tiles = (size_t)p.N * p.tiles_y * p.tiles_x * p.co_blocks;
     const dim3 grid((unsigned)(tiles < 256 ? tiles : 256));
     const size_t lds = ssie_wino_lds_bytes();
-    bool up = p.Wv >= 1900;               // (the DMA table holds hy * Wv + hx in 15 bits; wider images take the arithmetic decode)
-    for (int s = 0; s < p.nsrc; ++s) up = up || p.src[s].sy != 1.f || p.src[s].sx != 1.f;
+    // the DMA table holds a slot's byte offset from the tile origin in 24 bits (18 halo rows); larger images take the arithmetic decode
+    bool up = false;
+    for (int s = 0; s < p.nsrc; ++s)
+        up = up || p.src[s].sy != 1.f || p.src[s].sx != 1.f || (size_t)(W_HPH * p.Wv + W_HPW) * p.src[s].cstride * 4 >= (1u << 24) ||
+             (size_t)p.Hv * p.Wv * p.src[s].cstride * 4 >= (1u << 31);       // (and an image must fit a 32-bit num_records)
     if (p.nsrc == 1 && !up) hipLaunchKernelGGL((conv_wino_kernel<true, false>), grid, dim3(512), lds, st, p);
     else if (p.nsrc == 1) hipLaunchKernelGGL((conv_wino_kernel<true, true>), grid, dim3(512), lds, st, p);
     else if (!up) hipLaunchKernelGGL((conv_wino_kernel<false, false>), grid, dim3(512), lds, st, p);

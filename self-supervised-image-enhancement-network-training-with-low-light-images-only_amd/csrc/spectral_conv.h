@@ -9,15 +9,15 @@
 
 // tiles per image (and the tile grid)
 int ssie_spec_tiles(int H, int W, int* tiles_y, int* tiles_x);
-// in (N,H,W,cs) -> out[f][m0 + tile][Cp] (complex), Mtot tiles per frequency; halo = 1: windows start 4 pixels before the tile
+// in (N,H,W,cs) -> out[m0 + tile][f][Cp] (complex, tile-major), Mtot tiles in the tensor; halo = 1: windows start 4 pixels before the tile
 // (forward / data gradient), 0: the 24 x 24 tile itself, zero-padded (weight gradient)
 int ssie_launch_spec_fft(const float* in, int cs, int Cp, int N, int H, int W, int halo, float2* out, int m0, int Mtot, hipStream_t st);
-// Yf[f][m0 + tile][Np] -> out (N,H,W,cs): valid 24 x 24 block of every tile, channels < Cout (+ bias | += )
+// Yf[m0 + tile][f][Np] -> out (N,H,W,cs): valid 24 x 24 block of every tile, channels < Cout (+ bias | += )
 int ssie_launch_spec_ifft(const float2* Yf, int m0, int Mtot, int Np, int N, int H, int W, float* out, int cs, int Cout, const float* bias,
                           int accumulate, hipStream_t st);
 // w (Cout,Cin,9,9) -> Bf[f][Kp][Np] (forward) and, when Bd != null, Bd[f][Np][Kp] (data gradient)
 int ssie_launch_spec_weights(const float* w, int Cout, int Cin, int Kp, int Np, float2* Bf, float2* Bd, hipStream_t st);
-// C[f][mc0 + m][n] = sum_k A[f][ma0 + m][k] B[f][k][n], m < M; A / C hold Ma / Mc rows per frequency
+// C[mc0 + m][f][n] = sum_k A[ma0 + m][f][k] B[f][k][n], m < M (A / C tile-major; Ma / Mc = their tile counts)
 int ssie_launch_spec_gemm(const float2* A, int Ma, int ma0, const float2* B, float2* C, int Mc, int mc0, int M, int Kp, int Np, hipStream_t st);
 // dw (Cout = 64, Cin, 9, 9) += correlation of the gradient tiles with the input windows; dWs = (nslices * NF + 9 * 17) * Kp * 64 complex scratch
 int ssie_launch_spec_wgrad(const float2* Xf, const float2* Gf, float2* dWs, int M, int Kp, int nslices, int Cout, int Cin, float* dw, hipStream_t st);

@@ -7,7 +7,10 @@
 // the spectral result is CLOSER to the fp64 reference than the direct fp32 sum of 2 511 products (2.7e-7 vs 2.4e-6 of the
 // tensor's maximum, measured on the parity fixtures).  The work becomes HBM-bound streaming of spectral tensors:
 //
-//   spec_fft_tiles      x (N,H,W,C) -> X^[f][m][c]      32 x 32 real FFT of every tile window, half spectrum f = ky*17 + kx
+//   spec_fft_tiles      x (N,H,W,C) -> X^[m][f][c]      32 x 32 real FFT of every tile window, half spectrum f = ky*17 + kx
+//                       (every spectral tensor is TILE-major: a tile's 544 bins are one contiguous block, so the transform kernels -
+//                       which own a tile - stream it, and the per-frequency GEMMs read / write whole 256- or 512-byte channel rows
+//                       with f as the fastest grid index, i.e. neighbouring workgroups touch neighbouring rows)
 //   spec_weights        w (Co,Ci,9,9) -> B[f][ci][co] = conj(FFT(w padded)), B'[f][co][ci] = conj(FFT(flipped w))
 //   spec_gemm           Y^[f][m][n] = sum_k A[f][m][k] * B[f][k][n]   (complex, per frequency; as a real GEMM on the fp32 MFMA)
 //   spec_ifft_out       Y^ -> y (N,H,W,Co): inverse transform, the 24 x 24 valid block of every tile (+ bias | accumulate)
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256) void spec_fft_tiles_kernel(const float* __rest
     const size_t m = (size_t)m0 + mloc;
     for (int idx = tid; idx < NF * CG; idx += 256) {
         const int c = idx & (CG - 1), f = idx >> 3;
-        out[((size_t)f * Mtot + m) * Cp + c0 + c] = Cx[c * PS + f];     // f = ky * KX + kx is the in-plane offset
+        out[(m * NF + f) * Cp + c0 + c] = Cx[c * PS + f];               // f = ky * KX + kx is the in-plane offset
     }
 }
 
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256) void spec_ifft_out_kernel(const float2* __rest
     const size_t m = (size_t)m0 + mloc;
     for (int idx = tid; idx < NF * CG; idx += 256) {
         const int c = idx & (CG - 1), f = idx >> 3;
-        Cx[c * PS + f] = (c0 + c < Np) ? Yf[((size_t)f * Mtot + m) * Np + c0 + c] : make_float2(0.f, 0.f);
+        Cx[c * PS + f] = (c0 + c < Np) ? Yf[(m * NF + f) * Np + c0 + c] : make_float2(0.f, 0.f);
     }
     __syncthreads();
     if (tid < CG * KX) {
@@ -226,7 +229,7 @@ __global__ void spec_weights_kernel(const float* __restrict__ w, int Cout, int C
 //   B (cols = 32 n):        Re tile: h ? -Bi[k][n] : Br[k][n];   Im tile: h ? Br[k][n] : Bi[k][n]
 // so a k step costs one 8-byte LDS read per operand and two MFMAs per wave.  Workgroup = 4 waves = (4 / NT) m-tiles x NT n-tiles
 // of 32; K in chunks of 32 staged in LDS (A rows padded to 33 complex: conflict-free column reads).
-// grid (ceil(M / (128 / NT)), NF, Np / (32 NT))
+// grid (NF, ceil(M / (128 / NT)), Np / (32 NT)): f is the fastest index (see the layout note at the top)
 template <int NT>
 __global__ __launch_bounds__(256) void spec_gemm_kernel(const float2* __restrict__ A, const float2* __restrict__ B, float2* __restrict__ C,
                                                         int M, int Kp, int Np, int Ma, int ma0, int Mc, int mc0)
@@ -237,9 +240,10 @@ __global__ __launch_bounds__(256) void spec_gemm_kernel(const float2* __restrict
     __shared__ float2 Bs[32 * NB];                 // [k][n]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, li = lane & 31;
     const int wm = wave / NT, wn = wave % NT;
-    const int f = blockIdx.y, mb = blockIdx.x * MB, nb = blockIdx.z * NB;
-    const float2* Af = A + ((size_t)f * Ma + ma0) * Kp;
+    const int f = blockIdx.x, mb = blockIdx.y * MB, nb = blockIdx.z * NB;
+    const float2* Af = A + ((size_t)ma0 * NF + f) * Kp;          // row m of this frequency: Af + m * NF * Kp
     const float2* Bfp = B + (size_t)f * Kp * Np + nb;
+    const size_t arow = (size_t)NF * Kp, crow = (size_t)NF * Np;
     f32x16 cre, cim;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { cre[r] = 0.f; cim[r] = 0.f; }
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(256) void spec_gemm_kernel(const float2* __restrict
         __syncthreads();
         for (int idx = tid; idx < MB * 32; idx += 256) {
             const int mm = idx >> 5, kk = idx & 31;
-            As[mm * 33 + kk] = (mb + mm < M && k0 + kk < Kp) ? Af[(size_t)(mb + mm) * Kp + k0 + kk] : make_float2(0.f, 0.f);
+            As[mm * 33 + kk] = (mb + mm < M && k0 + kk < Kp) ? Af[(size_t)(mb + mm) * arow + k0 + kk] : make_float2(0.f, 0.f);
         }
         for (int idx = tid; idx < 32 * NB; idx += 256) {
             const int kk = idx / NB, nn = idx - kk * NB;
@@ -263,11 +267,11 @@ __global__ __launch_bounds__(256) void spec_gemm_kernel(const float2* __restrict
         }
     }
     // accumulator: lane (col = li = n, h), register r = row m_local = (r & 3) + 8 (r >> 2) + 4 h
-    float2* Cf = C + ((size_t)f * Mc + mc0) * Np + nb + wn * 32 + li;
+    float2* Cf = C + ((size_t)mc0 * NF + f) * Np + nb + wn * 32 + li;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = mb + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < M) Cf[(size_t)m * Np] = make_float2(cre[r], cim[r]);
+        if (m < M) Cf[(size_t)m * crow] = make_float2(cre[r], cim[r]);
     }
 }
 
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(256) void spec_gemm_kernel(const float2* __restrict
 //   A (rows = 32 output channels n):   h ? Gi[m][n] : Gr[m][n]
 //   B (cols = 32 input channels k):    Re tile: h ? Xi[m][k] : Xr[m][k];   Im tile: h ? -Xr[m][k] : Xi[m][k]
 // so a tile costs three 8-byte loads per lane (two G halves of 32 channels, one X) and four MFMAs (2 n-tiles x {Re, Im}),
-// straight from global memory (each row of G^ / X^ is one coalesced 512 / 256 byte segment).  grid (NF, slices, Kp / 32);
+// straight from global memory (each (tile, frequency) row of G^ / X^ is one coalesced 512 / 256 byte segment).  grid (NF, slices, Kp / 32);
 // the four waves of a workgroup take every fourth tile and are summed through LDS in fixed order (deterministic).
 __global__ __launch_bounds__(256) void spec_wgrad_reduce_kernel(const float2* __restrict__ Xf, const float2* __restrict__ Gf, float2* __restrict__ dW,
                                                                 int M, int Kp, int nslices)
@@ -294,14 +298,15 @@ __global__ __launch_bounds__(256) void spec_wgrad_reduce_kernel(const float2* __
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const float2* Xp = Xf + (size_t)f * M * Kp + k0 + li;
-    const float2* Gp = Gf + (size_t)f * M * Np + li;
+    const float2* Xp = Xf + (size_t)f * Kp + k0 + li;            // tile m: + m * NF * Kp
+    const float2* Gp = Gf + (size_t)f * Np + li;
+    const size_t xrow = (size_t)NF * Kp, grow = (size_t)NF * Np;
     constexpr int U = 4;                           // tiles per batch; the NEXT batch's 12 loads are in flight under this batch's 16 MFMAs
     float2 x[2][U], g0[2][U], g1[2][U];
 #define WG_LOAD(BUF, M0)                                                                                  \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                       \
         const int mm_ = min((M0) + u, mend - 1);                                                          \
-        x[BUF][u] = Xp[(size_t)mm_ * Kp]; g0[BUF][u] = Gp[(size_t)mm_ * Np]; g1[BUF][u] = Gp[(size_t)mm_ * Np + 32]; \
+        x[BUF][u] = Xp[(size_t)mm_ * xrow]; g0[BUF][u] = Gp[(size_t)mm_ * grow]; g1[BUF][u] = Gp[(size_t)mm_ * grow + 32]; \
     }
 #define WG_MFMA(BUF, M0)                                                                                  \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                       \
@@ -438,8 +443,9 @@ int ssie_launch_spec_weights(const float* w, int Cout, int Cin, int Kp, int Np, 
 int ssie_launch_spec_gemm(const float2* A, int Ma, int ma0, const float2* B, float2* C, int Mc, int mc0, int M, int Kp, int Np, hipStream_t st)
 {
     if (Kp % 8 || Np % 32) return 96;
-    if (Np % 64 == 0) hipLaunchKernelGGL(spec_gemm_kernel<2>, dim3((M + 63) / 64, NF, Np / 64), dim3(256), 0, st, A, B, C, M, Kp, Np, Ma, ma0, Mc, mc0);
-    else hipLaunchKernelGGL(spec_gemm_kernel<1>, dim3((M + 127) / 128, NF, Np / 32), dim3(256), 0, st, A, B, C, M, Kp, Np, Ma, ma0, Mc, mc0);
+    if ((M + 63) / 64 > 65535) return 97;
+    if (Np % 64 == 0) hipLaunchKernelGGL(spec_gemm_kernel<2>, dim3(NF, (M + 63) / 64, Np / 64), dim3(256), 0, st, A, B, C, M, Kp, Np, Ma, ma0, Mc, mc0);
+    else hipLaunchKernelGGL(spec_gemm_kernel<1>, dim3(NF, (M + 127) / 128, Np / 32), dim3(256), 0, st, A, B, C, M, Kp, Np, Ma, ma0, Mc, mc0);
     return hipGetLastError() == hipSuccess ? 0 : 98;
 }
 
