@@ -167,11 +167,13 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const float* __restr
 {
     __shared__ __attribute__((aligned(16))) unsigned short Kh[AK_ST][16];             // [key][dim]
     __shared__ __attribute__((aligned(16))) unsigned short Vt[AK_ST / 32][16][AV_LD];  // [32-key block][dim][permuted key]
-    __shared__ float mg[3][10][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, li = lane & 31;
     const int head = blockIdx.y, n = blockIdx.z;
-    const int qi = blockIdx.x * 32 + li;
+    // 128 queries per workgroup: every wave owns 32 queries and walks ALL keys of a staged slab.  (With the four waves sharing 32
+    // queries and splitting the keys, a workgroup converted and staged the whole K / V of its head for 32 queries: 2 048
+    // workgroups x 2 MB at 16 384 tokens - the staging, not the MFMAs or the softmax, was most of the kernel.)
+    const int qi = blockIdx.x * 128 + wave * 32 + li;
     const float* base = qkv + (size_t)n * T * qs;
     const float LOG2E = 1.4426950408889634f;
 
@@ -210,8 +212,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const float* __restr
         }
         __syncthreads();
 #pragma unroll
-        for (int sub = 0; sub < AK_W / 32; ++sub) {
-            const int lr = wave * AK_W + sub * 32;
+        for (int sub = 0; sub < AK_ST / 32; ++sub) {
+            const int lr = sub * 32;
             const int kb = k0 + lr;
             if (kb >= T) break;
             const uint4 ka = *(const uint4*)&Kh[lr + li][8 * h];
@@ -248,33 +250,11 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const float* __restr
         }
     }
     lsum += __shfl_xor(lsum, 32);
-    if (wave > 0) {
-        mg[wave - 1][0][lane] = m; mg[wave - 1][1][lane] = lsum;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) mg[wave - 1][2 + r][lane] = oacc[r];
-    }
-    __syncthreads();
-    if (wave == 0) {
-        float mt = m;
-#pragma unroll
-        for (int w = 0; w < 3; ++w) mt = fmaxf(mt, mg[w][0][lane]);
-        const float f0 = __builtin_amdgcn_exp2f(m - mt);
-        float ltot = lsum * f0;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) oacc[r] *= f0;
-#pragma unroll
-        for (int w = 0; w < 3; ++w) {
-            const float f = __builtin_amdgcn_exp2f(mg[w][0][lane] - mt);
-            ltot += mg[w][1][lane] * f;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) oacc[r] += mg[w][2 + r][lane] * f;
-        }
-        if (qi < T) {
-            const float inv = 1.f / ltot;
-            unsigned short* op = o + ((size_t)n * T + qi) * os + head * AT_D + 4 * h;
-            *(uint2*)op = make_uint2(at_pack2(oacc[0] * inv, oacc[1] * inv), at_pack2(oacc[2] * inv, oacc[3] * inv));
-            *(uint2*)(op + 8) = make_uint2(at_pack2(oacc[4] * inv, oacc[5] * inv), at_pack2(oacc[6] * inv, oacc[7] * inv));
-        }
+    if (qi < T) {
+        const float inv = 1.f / lsum;
+        unsigned short* op = o + ((size_t)n * T + qi) * os + head * AT_D + 4 * h;
+        *(uint2*)op = make_uint2(at_pack2(oacc[0] * inv, oacc[1] * inv), at_pack2(oacc[2] * inv, oacc[3] * inv));
+        *(uint2*)(op + 8) = make_uint2(at_pack2(oacc[4] * inv, oacc[5] * inv), at_pack2(oacc[6] * inv, oacc[7] * inv));
     }
 }
 
@@ -399,7 +379,7 @@ int ssie_launch_attn_fwd(const float* qkv, int qs, float* o, int os, float* lse,
 // qkv fp32 (N*T, qs); o bf16 (N*T, os)
 int ssie_launch_attn_fwd_bf16(const float* qkv, int qs, void* o, int os, int N, int T, hipStream_t st)
 {
-    dim3 grid((T + 31) / 32, 4, N);
+    dim3 grid((T + 127) / 128, 4, N);
     hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid, dim3(256), 0, st, qkv, qs, (unsigned short*)o, os, T, 0.25f);
     return hipGetLastError() == hipSuccess ? 0 : 63;
 }

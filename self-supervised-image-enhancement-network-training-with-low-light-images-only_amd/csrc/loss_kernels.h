@@ -40,6 +40,7 @@ int ssie_launch_product_node(const float* gS, int s_cs, const float* RL, float* 
 int ssie_launch_compose(const float* RL, int rl_cs, const float* D, int d_cs, float* S, int s_cs, long npix, int B, hipStream_t st);
 // fp32 -> bf16 (round to nearest even), n elements, n % 4 == 0 (inference path: input cube, attention output)
 int ssie_launch_to_bf16(const float* src, void* dst, long n, hipStream_t st);
+int ssie_launch_ingest_bf16(const float* x, long sn, long sc, long sh, long sw, void* out, int N, int C, int H, int W, int cs8, hipStream_t st);
 int ssie_launch_ingest(const float* x, long sn, long sc, long sh, long sw, float* out, int N, int C, int H, int W, int cs, hipStream_t st);
 int ssie_launch_mask_axpy(const float* src, int src_cs, const float* y, int y_cs, int mode, float* dst, int dst_cs,
                           long npix, int C, int accumulate, hipStream_t st);

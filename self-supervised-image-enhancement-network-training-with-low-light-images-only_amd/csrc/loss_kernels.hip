@@ -880,6 +880,34 @@ __global__ void to_bf16_kernel(const f32x4* __restrict__ src, uint2* __restrict_
     }
 }
 
+// logical (N,C,H,W) fp32 tensor with arbitrary element strides -> dense NHWC bf16 with zero channel padding (cs8 channels per
+// pixel, a multiple of 8): the bf16 enhance-only path's ingest + conversion in one pass (the fp32 NHWC copy is not needed there)
+__global__ void ingest_bf16_kernel(const float* __restrict__ x, long sn, long sc, long sh, long sw,
+                                   uint2* __restrict__ out, int N, int C, int H, int W, int cs8)
+{
+    const int q4 = cs8 >> 2;                             // 4-channel groups per pixel
+    const long total = (long)N * H * W * q4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % q4); long r = i / q4;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H); const long n = r / H;
+        const float* px = x + n * sn + h * sh + w * sw;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int c = 4 * q + j; v[j] = c < C ? px[c * sc] : 0.f; }
+        out[i] = make_uint2(ssie_pack2bf(v[0], v[1]), ssie_pack2bf(v[2], v[3]));
+    }
+}
+
+int ssie_launch_ingest_bf16(const float* x, long sn, long sc, long sh, long sw, void* out, int N, int C, int H, int W, int cs8, hipStream_t st)
+{
+    if (cs8 % 8) return 73;
+    const long total = (long)N * H * W * (cs8 / 4);
+    long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(ingest_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, sn, sc, sh, sw, (uint2*)out, N, C, H, W, cs8);
+    return hipGetLastError() == hipSuccess ? 0 : 74;
+}
+
 int ssie_launch_to_bf16(const float* src, void* dst, long n, hipStream_t st)
 {
     if (n % 4) return 71;

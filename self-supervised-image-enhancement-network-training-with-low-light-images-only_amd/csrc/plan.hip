@@ -768,11 +768,7 @@ int build_all(Plan& pl, bool dry)
     pl.fwd16.clear();
     const bool tail_ok = pl.fused_tail && ssie_tail_supported(pl.H, pl.W, pl.H2, pl.W2, pl.H4, pl.W4) != 0;
     if (pl.CX % 8 == 0 && pl.CRL % 8 == 0) {      // bf16 pixels are read in 16-byte (8-channel) slots; e.g. B = 31, 63, 127
-        b.h16 = true;
-        if (!b.dry) {
-            const float* xf = pl.buf("x"); float* xh = pl.buf("xh"); const long ne = (long)pl.N * pl.H * pl.W * pl.CX;
-            pl.fwd16.push_back(Fn([=](hipStream_t st) { return ssie_launch_to_bf16(xf, xh, ne, st); }));
-        }
+        b.h16 = true;           // (the bf16 copy of the input cube is written by ingest16(): strided fp32 in, NHWC bf16 out, one pass)
         CK(build_decomposition_fwd(b, pl.fwd16, "x", 1));
         CK(build_illum_fwd(b, pl.fwd16, tail_ok));
         b.h16 = false;
@@ -964,6 +960,13 @@ static int ingest(Plan* pl, const float* x, const long* strides4, hipStream_t st
                ? SSIE_E_LAUNCH : 0;
 }
 
+// bf16 enhance-only path: the input goes straight into the bf16 NHWC buffer "xh" (the fp32 copy "x" is not written)
+static int ingest16(Plan* pl, const float* x, const long* strides4, hipStream_t st)
+{
+    return ssie_launch_ingest_bf16(x, strides4[0], strides4[1], strides4[2], strides4[3], pl->buf("xh"), pl->N, pl->B, pl->H, pl->W,
+                                   ssie_round_up(pl->CX, 8), st) ? SSIE_E_LAUNCH : 0;
+}
+
 extern "C" int ssie_plan_enhance_fwd(void* h, const float* x, const long* strides4, void* stream)
 {
     Plan* pl = (Plan*)h;
@@ -983,7 +986,7 @@ extern "C" int ssie_plan_enhance_fwd_bf16(void* h, const float* x, const long* s
     if (pl->fwd16.empty()) return SSIE_E_SHAPE;      // band count not a multiple of 8 after padding: use the fp32 path
     hipStream_t st = (hipStream_t)stream;
     CK(pack_all_bf16(pl, st));
-    CK(ingest(pl, x, strides4, st));
+    CK(ingest16(pl, x, strides4, st));
     return run_ops(pl->fwd16, st);
 }
 
@@ -1104,7 +1107,7 @@ extern "C" int ssie_plan_profile_list(void* h, const float* x, const long* strid
     std::vector<hipEvent_t> ev(seq.size() + 1);
     for (auto& e : ev) hipEventCreate(&e);
     if (which == 1) pack_all_bf16(pl, st); else pack_all(pl, st);
-    ingest(pl, x, strides4, st);
+    if (which == 1) ingest16(pl, x, strides4, st); else ingest(pl, x, strides4, st);
     hipEventRecord(ev[0], st);
     for (size_t i = 0; i < seq.size(); ++i) { seq[i](st); hipEventRecord(ev[i + 1], st); }
     hipStreamSynchronize(st);
