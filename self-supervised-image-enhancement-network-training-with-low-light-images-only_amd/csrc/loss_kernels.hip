@@ -748,6 +748,31 @@ __global__ void upsample_adjoint_kernel(const float* __restrict__ src, int Hv, i
     }
 }
 
+// the same adjoint when the up-sampling factor is an exact integer F (even image sizes: every pyramid level of the 128 x 128
+// training patches): src index = floor(dst / F), so dst pixel (y, x) is the sum of the F x F block below it.  One thread per
+// (pixel, channel quad), 16-byte accesses; the general kernel above searches a 5 x 5 candidate window per element.
+template <int F>
+__global__ void upsample_adjoint_exact_kernel(const float* __restrict__ src, int src_cs, float* __restrict__ dst, int Hs, int Ws, int dst_cs,
+                                              int N, int C4, int accumulate)
+{
+    const long total = (long)N * Hs * Ws * C4;
+    const int Wv = Ws * F, Hv = Hs * F;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % C4); long r = i / C4;
+        const int x = (int)(r % Ws); r /= Ws;
+        const int y = (int)(r % Hs); const long n = r / Hs;
+        f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < F; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < F; ++dx)
+                s4 += *(const f32x4*)(src + ((n * Hv + (long)y * F + dy) * Wv + (long)x * F + dx) * src_cs + 4 * q);
+        float* d = dst + ((n * Hs + y) * (long)Ws + x) * dst_cs + 4 * q;
+        if (accumulate) s4 += *(const f32x4*)d;
+        *(f32x4*)d = s4;
+    }
+}
+
 // torch.optim.Adam defaults (model.py:213): p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             long n, float gscale, float b1, float b2, float step_size, float inv_sqrt_bc2, float eps)
@@ -855,6 +880,15 @@ int ssie_launch_mask_axpy(const float* src, int src_cs, const float* y, int y_cs
 int ssie_launch_upsample_adjoint(const float* src, int Hv, int Wv, int src_cs, float* dst, int Hs, int Ws, int dst_cs,
                                  int N, int C, int accumulate, hipStream_t st)
 {
+    const bool al = C % 4 == 0 && src_cs % 4 == 0 && dst_cs % 4 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
+    if (al && Hv == 2 * Hs && Wv == 2 * Ws) {
+        hipLaunchKernelGGL(upsample_adjoint_exact_kernel<2>, dim3(grid_for((long)N * Hs * Ws * (C / 4), 256)), dim3(256), 0, st, src, src_cs, dst, Hs, Ws, dst_cs, N, C / 4, accumulate);
+        return hipGetLastError() == hipSuccess ? 0 : 47;
+    }
+    if (al && Hv == 4 * Hs && Wv == 4 * Ws) {
+        hipLaunchKernelGGL(upsample_adjoint_exact_kernel<4>, dim3(grid_for((long)N * Hs * Ws * (C / 4), 256)), dim3(256), 0, st, src, src_cs, dst, Hs, Ws, dst_cs, N, C / 4, accumulate);
+        return hipGetLastError() == hipSuccess ? 0 : 47;
+    }
     const float sy = (Hs == Hv) ? 1.f : (float)Hs / (float)Hv, sx = (Ws == Wv) ? 1.f : (float)Ws / (float)Wv;
     hipLaunchKernelGGL(upsample_adjoint_kernel, dim3(grid_for((long)N * Hs * Ws * C, 256)), dim3(256), 0, st,
                        src, Hv, Wv, src_cs, dst, Hs, Ws, dst_cs, N, C, sy, sx, accumulate);

@@ -50,6 +50,7 @@ CASES = {
     "b31_64": (2, 31, 64, 64, O.JYU_COEFS),
     "b8_32x64": (3, 8, 32, 64, O.JYU_COEFS),
     "b8_24x40": (2, 8, 24, 40, O.JYU_COEFS),
+    "b8_20x28": (2, 8, 20, 28, O.JYU_COEFS),          # pyramid 20x28 -> 10x14 -> 5x7 -> 3x4: the odd levels take the general up-sampling adjoint
     "b31_128": (1, 31, 128, 128, O.JYU_COEFS),
     "b256_64": (1, 256, 64, 64, O.JYU_COEFS),
     "b5_256": (1, 5, 256, 256, O.JYU_COEFS),
