@@ -78,7 +78,7 @@ def dominant_traffic(kernel_substr, workload):
     command, MI355X_MICROARCH.md HBM section) from the committed profile of THIS round and THIS workload (final pass first,
     then the mid-round one); PMC counters cannot be read from inside the process.  -> (bytes or None, kernel name, source file)"""
     try:
-        for tag in ("r02_final", "r02_mid"):
+        for tag in ("r03_final", "r03_mid", "r02_final"):
             f = os.path.join(ROOT, "profiles", f"{tag}_{workload}_hbm_traffic.json")
             if not os.path.exists(f):
                 continue

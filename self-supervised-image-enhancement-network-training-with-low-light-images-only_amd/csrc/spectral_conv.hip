@@ -247,17 +247,28 @@ __global__ __launch_bounds__(256) void spec_gemm_kernel(const float2* __restrict
     f32x16 cre, cim;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { cre[r] = 0.f; cim[r] = 0.f; }
+    // K in chunks of 32; the NEXT chunk's operands are fetched into registers before this chunk's MFMAs and written to LDS after them
+    // (one chunk at 31 bands; eight at 256, where the exposed load latency of the single-buffered loop was a third of the kernel)
+    constexpr int NA = MB * 32 / 256, NBR = 32 * NB / 256;
+    float2 ar[NA], br[NBR];
+#define SG_FETCH(K0)                                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < NA; ++i_) {                                                           \
+        const int idx = i_ * 256 + tid, mm = idx >> 5, kk = idx & 31;                                             \
+        ar[i_] = (mb + mm < M && (K0) + kk < Kp) ? Af[(size_t)(mb + mm) * arow + (K0) + kk] : make_float2(0.f, 0.f); \
+    }                                                                                                             \
+    _Pragma("unroll") for (int i_ = 0; i_ < NBR; ++i_) {                                                          \
+        const int idx = i_ * 256 + tid, kk = idx / NB, nn = idx - kk * NB;                                        \
+        br[i_] = ((K0) + kk < Kp) ? Bfp[(size_t)((K0) + kk) * Np + nn] : make_float2(0.f, 0.f);                   \
+    }
+#define SG_STORE                                                                                                  \
+    _Pragma("unroll") for (int i_ = 0; i_ < NA; ++i_) { const int idx = i_ * 256 + tid; As[(idx >> 5) * 33 + (idx & 31)] = ar[i_]; } \
+    _Pragma("unroll") for (int i_ = 0; i_ < NBR; ++i_) Bs[i_ * 256 + tid] = br[i_];
+    SG_FETCH(0)
+    SG_STORE
+    __syncthreads();
     for (int k0 = 0; k0 < Kp; k0 += 32) {
-        __syncthreads();
-        for (int idx = tid; idx < MB * 32; idx += 256) {
-            const int mm = idx >> 5, kk = idx & 31;
-            As[mm * 33 + kk] = (mb + mm < M && k0 + kk < Kp) ? Af[(size_t)(mb + mm) * arow + k0 + kk] : make_float2(0.f, 0.f);
-        }
-        for (int idx = tid; idx < 32 * NB; idx += 256) {
-            const int kk = idx / NB, nn = idx - kk * NB;
-            Bs[idx] = (k0 + kk < Kp) ? Bfp[(size_t)(k0 + kk) * Np + nn] : make_float2(0.f, 0.f);
-        }
-        __syncthreads();
+        const bool more = k0 + 32 < Kp;
+        if (more) { SG_FETCH(k0 + 32) }
 #pragma unroll 8
         for (int kk = 0; kk < 32; ++kk) {
             const float2 a = As[(wm * 32 + li) * 33 + kk], bq = Bs[kk * NB + wn * 32 + li];
@@ -265,7 +276,14 @@ __global__ __launch_bounds__(256) void spec_gemm_kernel(const float2* __restrict
             cre = __builtin_amdgcn_mfma_f32_32x32x2f32(av, h ? -bq.y : bq.x, cre, 0, 0, 0);
             cim = __builtin_amdgcn_mfma_f32_32x32x2f32(av, h ? bq.x : bq.y, cim, 0, 0, 0);
         }
+        if (more) {
+            __syncthreads();                       // every wave is done reading this chunk
+            SG_STORE
+            __syncthreads();
+        }
     }
+#undef SG_FETCH
+#undef SG_STORE
     // accumulator: lane (col = li = n, h), register r = row m_local = (r & 3) + 8 (r >> 2) + 4 h
     float2* Cf = C + ((size_t)mc0 * NF + f) * Np + nb + wn * 32 + li;
 #pragma unroll
@@ -362,6 +380,86 @@ __global__ __launch_bounds__(256) void spec_wgrad_reduce_kernel(const float2* __
     }
 }
 
+// The same reduction for wide inputs (Kp >= 128, e.g. 256 bands): a workgroup owns ALL tiles of its (frequency, slice) and its four
+// waves split the INPUT channels (KT blocks of 32 each) instead of the tiles, so G^ - which every k block needs whole - is read
+// once per 128 KT input channels instead of once per 32 (at 256 bands the kernel above reads G^ eight times: 7.8 GB of counter
+// traffic per launch against 3.2 GB of operands), and no cross-wave sum is needed.  grid (NF, slices, Kp / (128 KT)).
+template <int KT>
+__global__ __launch_bounds__(256) void spec_wgrad_reduce_wide_kernel(const float2* __restrict__ Xf, const float2* __restrict__ Gf, float2* __restrict__ dW,
+                                                                     int M, int Kp, int nslices)
+{
+    constexpr int Np = 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, li = lane & 31;
+    const int f = blockIdx.x, s = blockIdx.y, k0 = (blockIdx.z * 4 + wave) * KT * 32;
+    const int per = (M + nslices - 1) / nslices, mbeg = s * per, mend = min(M, mbeg + per);
+    f32x16 acc[KT][2][2];                          // [k block][n-tile][Re / Im]
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[kt][i][j][r] = 0.f;
+    const float2* Xp = Xf + (size_t)f * Kp + k0 + li;            // tile m: + m * NF * Kp
+    const float2* Gp = Gf + (size_t)f * Np + li;
+    const size_t xrow = (size_t)NF * Kp, grow = (size_t)NF * Np;
+    // every lane loads exactly the component it feeds: lane half h takes the real (h = 0) or imaginary (h = 1) part of G^ as the A
+    // operand and of X^ as the Re-tile B operand, and the OTHER part of X^ (negated for h = 1) as the Im-tile B operand - 4-byte
+    // loads, no per-lane select (written as h ? v.y : v.x on float2 arrays hipcc spilled the arrays to scratch to index them)
+    const float* Xq = (const float*)Xp + h;
+    const float* Xo = (const float*)Xp + (1 - h);
+    const float* Gq = (const float*)Gp + h;
+    const float sgn = h ? -1.f : 1.f;
+    constexpr int U = 4;                           // tiles per batch; the next batch's loads are in flight under this batch's MFMAs
+    float xr[2][U][KT], xo[2][U][KT], g0[2][U], g1[2][U];
+#define WW_LOAD(BUF, M0)                                                                                  \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                       \
+        const int mm_ = min((M0) + u, mend - 1);                                                          \
+        g0[BUF][u] = Gq[(size_t)mm_ * grow * 2]; g1[BUF][u] = Gq[(size_t)mm_ * grow * 2 + 64];            \
+        _Pragma("unroll") for (int kt = 0; kt < KT; ++kt) {                                               \
+            xr[BUF][u][kt] = Xq[(size_t)mm_ * xrow * 2 + 64 * kt]; xo[BUF][u][kt] = Xo[(size_t)mm_ * xrow * 2 + 64 * kt]; \
+        }                                                                                                 \
+    }
+#define WW_MFMA(BUF, M0)                                                                                  \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                       \
+        if ((M0) + u < mend) {                                                                            \
+            const float a0 = g0[BUF][u], a1 = g1[BUF][u];                                                 \
+            _Pragma("unroll") for (int kt = 0; kt < KT; ++kt) {                                           \
+                const float bre = xr[BUF][u][kt], bim = sgn * xo[BUF][u][kt];                             \
+                acc[kt][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bre, acc[kt][0][0], 0, 0, 0);    \
+                acc[kt][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bim, acc[kt][0][1], 0, 0, 0);    \
+                acc[kt][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bre, acc[kt][1][0], 0, 0, 0);    \
+                acc[kt][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bim, acc[kt][1][1], 0, 0, 0);    \
+            }                                                                                             \
+        }                                                                                                 \
+    }
+    int m = mbeg;
+    if (m < mend) WW_LOAD(0, m)
+    for (; m < mend; m += 2 * U) {                 // two batches per trip so that the buffer index is a compile-time constant
+        const int m1 = m + U;
+        if (m1 < mend) WW_LOAD(1, m1)
+        WW_MFMA(0, m)
+        if (m1 < mend) {
+            if (m1 + U < mend) WW_LOAD(0, m1 + U)
+            WW_MFMA(1, m1)
+        }
+    }
+#undef WW_LOAD
+#undef WW_MFMA
+    // accumulator layout: lane (col = li = input channel k, h), register r = row n_local = (r & 3) + 8 (r >> 2) + 4 h
+    float2* o = dW + ((size_t)s * NF + f) * Kp * Np;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                o[(size_t)(k0 + 32 * kt + li) * Np + n] = make_float2(acc[kt][i][0][r], acc[kt][i][1][r]);
+            }
+}
+
 // ---- weight gradient, inverse transform restricted to the 9 x 9 taps, in two separable stages ----------------------------
 // stage 1: E[ty][kx][k][n] = sum_s sum_ky dW^[s][ky][kx][k][n] e^{+2 pi i ky ty / 32}           (9 x 17 x Kp x 64 threads)
 // stage 2: dw[n][k][ty][tx] += (1/1024) sum_kx wgt(kx) Re(E[ty][kx][k][n] e^{+2 pi i kx tx / 32}), wgt = 1 for kx in {0, 16} else 2
@@ -452,7 +550,9 @@ int ssie_launch_spec_gemm(const float2* A, int Ma, int ma0, const float2* B, flo
 int ssie_launch_spec_wgrad(const float2* Xf, const float2* Gf, float2* dWs, int M, int Kp, int nslices, int Cout, int Cin, float* dw, hipStream_t st)
 {
     if (Kp % 32) return 99;
-    hipLaunchKernelGGL(spec_wgrad_reduce_kernel, dim3(NF, nslices, Kp / 32), dim3(256), 0, st, Xf, Gf, dWs, M, Kp, nslices);
+    if (Kp % 256 == 0) hipLaunchKernelGGL(spec_wgrad_reduce_wide_kernel<2>, dim3(NF, nslices, Kp / 256), dim3(256), 0, st, Xf, Gf, dWs, M, Kp, nslices);
+    else if (Kp % 128 == 0) hipLaunchKernelGGL(spec_wgrad_reduce_wide_kernel<1>, dim3(NF, nslices, Kp / 128), dim3(256), 0, st, Xf, Gf, dWs, M, Kp, nslices);
+    else hipLaunchKernelGGL(spec_wgrad_reduce_kernel, dim3(NF, nslices, Kp / 32), dim3(256), 0, st, Xf, Gf, dWs, M, Kp, nslices);
     float2* E = dWs + (size_t)nslices * NF * Kp * 64;          // [9][17][Kp][64] behind the slices
     const long t1 = (long)9 * KX * Kp * 64;
     hipLaunchKernelGGL(spec_wgrad_out1_kernel, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, st, (const float2*)dWs, nslices, Kp, E);

@@ -3,7 +3,7 @@
 # workloads.  Outputs land in gpurun_out/<tag>/; `python tools/make_profiles.py <tag>` (CPU, afterwards) turns them into the
 # committed summaries under profiles/.   usage: bash tools/run_profiles.sh r02_mid [workloads...]
 set -o pipefail
-TAG=${1:-r02}; shift
+TAG=${1:-r03}; shift
 WL=${@:-"train31 train256 infer1024_bf16"}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
