@@ -69,6 +69,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int bcol = tid % COB, brow = tid / COB;
     float bsum = 0.f;
 
+    // Plain (not up-sampled) sources are fetched through buffer descriptors (conv_wino.hip): one scalar resource per image whose
+    // num_records is the image's byte size - rows of the halo outside the image are out-of-range offsets and arrive as zeros - and
+    // ONE precomputed 32-bit byte offset per slot and thread (this kernel runs one wave per SIMD: registers are plentiful), so a
+    // slot costs one vector add instead of ~14 address instructions; tiles on the left / right border and partial channel blocks
+    // still compare the column / channel quad of a slot.
+    unsigned xoff[NX], goff[NG];
+    if (!UP) {
+#pragma unroll
+        for (int it = 0; it < NX; ++it) {
+            const int id = it * 256 + tid;
+            const unsigned pix = (unsigned)id / CI4, j = (unsigned)id % CI4;
+            const unsigned hy = (pix * 3641u) >> 16, hx = pix - hy * GW_HPW;
+            xoff[it] = ((hy * (unsigned)p.Wv + hx) * (unsigned)p.src.cstride + 4u * j) * 4u;
+        }
+#pragma unroll
+        for (int it = 0; it < NG; ++it) {
+            const int id = it * 256 + tid;
+            const unsigned pix = (unsigned)id / CO4, j = (unsigned)id % CO4;
+            const unsigned gy = pix / GW_TW, gx = pix % GW_TW;
+            goff[it] = ((gy * (unsigned)p.Wo + gx) * (unsigned)p.g_cstride + 4u * j) * 4u;
+        }
+    }
+#define GW_RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, (int)(bytes), 0x00020000)
+#define GW_BLDS(rs, lptr, vo) __builtin_amdgcn_raw_ptr_buffer_load_lds((rs), (__attribute__((address_space(3))) void*)(lptr), 16, (int)(vo), 0, 0, 0)
     // DMA of position tile TILE into buffer BUF: slot id = it * 256 + tid (the DMA writes LDS linearly) = (pixel, channel quad)
 #define GW_STAGE(TILE, BUF)                                                                                   \
     {                                                                                                         \
@@ -76,6 +100,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int tx_ = tt_ % p.tiles_x; tt_ /= p.tiles_x;                                                    \
         const int ty_ = tt_ % p.tiles_y, n_ = tt_ / p.tiles_y;                                                \
         const int a0_ = ty_ * GW_TH, b0_ = tx_ * GW_TW;                                                       \
+        if (!UP) {                                                                                            \
+            const __amdgpu_buffer_rsrc_t xr_ = GW_RSRC(p.src.ptr + (size_t)n_ * p.Hv * p.Wv * p.src.cstride,   \
+                                                       (unsigned)(p.Hv * p.Wv * p.src.cstride) * 4u);         \
+            const unsigned xb_ = (unsigned)((((a0_ - 1) * p.Wv + b0_ - 1) * p.src.cstride + p.src.coff + ci0) * 4); \
+            const unsigned xlo_ = b0_ == 0, xn_ = min(GW_HPW, p.Wv - b0_ + 1) - xlo_;                         \
+            const unsigned jn_ = (unsigned)((p.src.C - ci0 + 3) >> 2);                                        \
+            if (xn_ == (unsigned)GW_HPW && jn_ >= (unsigned)CI4) {                                            \
+                _Pragma("unroll") for (int it_ = 0; it_ < NX; ++it_)                                          \
+                    if (NX * 256 == GW_HPH * GW_HPW * CI4 || it_ * 256 + tid < GW_HPH * GW_HPW * CI4)         \
+                        GW_BLDS(xr_, (f32x4*)(Xs0 + (BUF) * XSZ) + it_ * 256 + wave * 64, xb_ + xoff[it_]);   \
+            } else {                                                                                          \
+                _Pragma("unroll") for (int it_ = 0; it_ < NX; ++it_) {                                        \
+                    const unsigned id_ = it_ * 256 + tid, pix_ = id_ / CI4, j_ = id_ % CI4;                   \
+                    const unsigned hx_ = pix_ - ((pix_ * 3641u) >> 16) * GW_HPW;     /* column of the slot (border tiles only) */ \
+                    const bool ok_ = hx_ - xlo_ < xn_ && j_ < jn_;                                            \
+                    if (NX * 256 == GW_HPH * GW_HPW * CI4 || it_ * 256 + tid < GW_HPH * GW_HPW * CI4)         \
+                        GW_BLDS(xr_, (f32x4*)(Xs0 + (BUF) * XSZ) + it_ * 256 + wave * 64, ok_ ? xb_ + xoff[it_] : 0x80000000u); \
+                }                                                                                             \
+            }                                                                                                 \
+            const __amdgpu_buffer_rsrc_t gr_ = GW_RSRC(p.g + (size_t)n_ * p.Ho * p.Wo * p.g_cstride,          \
+                                                       (unsigned)(p.Ho * p.Wo * p.g_cstride) * 4u);           \
+            const unsigned gb_ = (unsigned)(((a0_ * p.Wo + b0_) * p.g_cstride + p.g_coff + co0) * 4);          \
+            const unsigned gxn_ = min(GW_TW, p.Wo - b0_);                                                     \
+            const unsigned gjn_ = (unsigned)((((p.Cout + 3) & ~3) - co0 + 3) >> 2);                           \
+            if (gxn_ == (unsigned)GW_TW && gjn_ >= (unsigned)CO4) {                                           \
+                _Pragma("unroll") for (int it_ = 0; it_ < NG; ++it_)                                          \
+                    GW_BLDS(gr_, (f32x4*)(Gs0 + (BUF) * GSZ) + it_ * 256 + wave * 64, gb_ + goff[it_]);       \
+            } else {                                                                                          \
+                _Pragma("unroll") for (int it_ = 0; it_ < NG; ++it_) {                                        \
+                    const unsigned id_ = it_ * 256 + tid, gx_ = (id_ / CO4) % GW_TW, j_ = id_ % CO4;          \
+                    const bool ok_ = gx_ < gxn_ && j_ < gjn_;                                                 \
+                    GW_BLDS(gr_, (f32x4*)(Gs0 + (BUF) * GSZ) + it_ * 256 + wave * 64, ok_ ? gb_ + goff[it_] : 0x80000000u); \
+                }                                                                                             \
+            }                                                                                                 \
+        } else {                                                                                              \
         const int tbx_ = ((n_ * p.Hv + a0_ - 1) * p.Wv + b0_ - 1) * p.src.cstride + p.src.coff + ci0;         \
         const unsigned ylo_ = a0_ == 0, yn_ = min(GW_HPH, p.Hv - a0_ + 1) - ylo_;                             \
         const unsigned xlo_ = b0_ == 0, xn_ = min(GW_HPW, p.Wv - b0_ + 1) - xlo_;                             \
@@ -107,6 +166,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int off_ = tbg_ + (int)(gy_ * p.Wo + gx_) * p.g_cstride + 4 * (int)j_;                      \
             const unsigned long long a_ = (unsigned long long)(p.g + off_), m_ = ok_ ? ~0ull : 0ull;          \
             GLDS16G((const f32x4*)((a_ & m_) | (zp_ & ~m_)), (f32x4*)(Gs0 + (BUF) * GSZ) + it_ * 256 + wave * 64); \
+        }                                                                                                     \
         }                                                                                                     \
     }
 
@@ -172,6 +232,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     }
 #undef GW_STAGE
+#undef GW_RSRC
+#undef GW_BLDS
 
     if (do_bias) {
         __syncthreads();

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // U pieces: per-lane byte offset inside a piece pair (two (xi, q) rows of 32 float4), constant for the whole kernel
     const unsigned u_lane = (unsigned)(((lane >> 5) * p.Cout_pad + (lane & 31)) * 16);
 #define WN_RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, (int)(bytes), 0x00020000)
-#define WN_BLDS(rs, lptr, vo, so) __builtin_amdgcn_raw_ptr_buffer_load_lds((rs), (__attribute__((address_space(3))) void*)(lptr), 16, (vo), (so), 0, 0)
+#define WN_BLDS(rs, lptr, vo, so) __builtin_amdgcn_raw_ptr_buffer_load_lds((rs), (__attribute__((address_space(3))) void*)(lptr), 16, (int)(vo), (int)(so), 0, 0)
 #define WN_PREFETCH(CHUNK, N_, A0_, B0_, CO0_, BUF)                                                           \
     {                                                                                                         \
         f32x4* bbuf_ = Bs0 + (BUF) * W_BSZ;                                                                   \
