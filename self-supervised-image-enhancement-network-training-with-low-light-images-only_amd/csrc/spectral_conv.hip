@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void spec_wgrad_reduce_kernel(const float2* __
     const float2* Xp = Xf + (size_t)f * Kp + k0 + li;            // tile m: + m * NF * Kp
     const float2* Gp = Gf + (size_t)f * Np + li;
     const size_t xrow = (size_t)NF * Kp, grow = (size_t)NF * Np;
-    constexpr int U = 4;                           // tiles per batch; the NEXT batch's 12 loads are in flight under this batch's 16 MFMAs
+    constexpr int U = 8;                           // tiles per batch; the NEXT batch's 24 loads are in flight under this batch's 32 MFMAs
     float2 x[2][U], g0[2][U], g1[2][U];
 #define WG_LOAD(BUF, M0)                                                                                  \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                       \
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void spec_wgrad_reduce_wide_kernel(const float
     const float* Xo = (const float*)Xp + (1 - h);
     const float* Gq = (const float*)Gp + h;
     const float sgn = h ? -1.f : 1.f;
-    constexpr int U = 4;                           // tiles per batch; the next batch's loads are in flight under this batch's MFMAs
+    constexpr int U = 8;                           // tiles per batch; the next batch's loads are in flight under this batch's MFMAs
     float xr[2][U][KT], xo[2][U][KT], g0[2][U], g1[2][U];
 #define WW_LOAD(BUF, M0)                                                                                  \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                       \
