@@ -680,6 +680,38 @@ __global__ __launch_bounds__(256) void product_node_kernel(const float* __restri
     }
 }
 
+// the same node with 16-byte accesses: LPP lanes share a pixel, lane `sub` owning float4 `sub` of the band vector (nq <= LPP;
+// aligned tensors with channel strides that are multiples of 4); the band sum is an LPP-lane butterfly, and the lane that owns
+// channel B (I_low) adds q to it inside its own float4, so every element is written by exactly one lane
+template <int LPP>
+__global__ __launch_bounds__(256) void product_node_vec_kernel(const float* __restrict__ gS, int s_cs,
+                                                               const float* __restrict__ RL, float* __restrict__ gRL, int rl_cs,
+                                                               const float* __restrict__ D, float* __restrict__ gD, int d_cs,
+                                                               long npix, int B)
+{
+    constexpr int PPB = 256 / LPP;
+    const int sub = threadIdx.x % LPP, grp = threadIdx.x / LPP;
+    const int nq = rl_cs >> 2, nqs = s_cs >> 2;
+    const bool own = sub < nq && 4 * sub <= B;             // quads up to the one that holds channel B
+    for (long pix0 = (long)blockIdx.x * PPB; pix0 < npix; pix0 += (long)gridDim.x * PPB) {
+        const long pix = pix0 + grp;
+        const bool live = pix < npix;
+        const long pc = live ? pix : npix - 1;
+        const float m = D[pc * d_cs] + RL[pc * rl_cs + B];
+        f32x4 r = {0.f, 0.f, 0.f, 0.f}, g = r, o = r;
+        if (own) { r = *(const f32x4*)(RL + pc * rl_cs + 4 * sub); o = *(const f32x4*)(gRL + pc * rl_cs + 4 * sub); }
+        if (own && sub < nqs) g = *(const f32x4*)(gS + pc * s_cs + 4 * sub);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (4 * sub + j < B) { q += g[j] * r[j]; o[j] += g[j] * m; }
+        q = grp_sum<LPP>(q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (4 * sub + j == B) o[j] += q;
+        if (live && own) *(f32x4*)(gRL + pc * rl_cs + 4 * sub) = o;
+        if (live && sub == 0) gD[pix * d_cs] += q;
+    }
+}
+
 // S = R*I_delta + R*I_low (model.py:233); pad channels of S stay zero
 __global__ void compose_kernel(const float* __restrict__ RL, int rl_cs, const float* __restrict__ D, int d_cs,
                                float* __restrict__ S, int s_cs, long npix, int B)
@@ -858,6 +890,14 @@ int ssie_launch_loss_finalize(const float* partials, int nblk, const float* fpar
 int ssie_launch_product_node(const float* gS, int s_cs, const float* RL, float* gRL, int rl_cs, const float* D, float* gD,
                              int d_cs, long npix, int B, hipStream_t st)
 {
+    const bool al = s_cs % 4 == 0 && rl_cs % 4 == 0 && B < rl_cs && (((uintptr_t)gS | (uintptr_t)RL | (uintptr_t)gRL) & 15) == 0;
+    const int nq = rl_cs / 4;
+    if (al && nq <= 64) {
+#define PN_LAUNCH(L) hipLaunchKernelGGL(product_node_vec_kernel<L>, dim3(grid_for(npix, 256 / L)), dim3(256), 0, st, gS, s_cs, RL, gRL, rl_cs, D, gD, d_cs, npix, B)
+        if (nq <= 8) PN_LAUNCH(8); else if (nq <= 16) PN_LAUNCH(16); else if (nq <= 32) PN_LAUNCH(32); else PN_LAUNCH(64);
+#undef PN_LAUNCH
+        return hipGetLastError() == hipSuccess ? 0 : 43;
+    }
     hipLaunchKernelGGL(product_node_kernel, dim3(grid_for(npix, 8)), dim3(256), 0, st, gS, s_cs, RL, gRL, rl_cs, D, gD, d_cs, npix, B);
     return hipGetLastError() == hipSuccess ? 0 : 43;
 }
