@@ -69,9 +69,7 @@ __device__ __forceinline__ void fft32(float2 (&v)[32])
     }
 }
 
-// channels per workgroup of the tile transforms: CG = 16 (512 threads, 70 KB of dynamic LDS, two workgroups per CU) wherever the
-// channel count allows - a workgroup's global accesses are then 64-byte (real tile) and 128-byte (spectrum) pieces per pixel / bin
-// instead of 32 / 64 - else CG = 8 (256 threads)
+constexpr int CG = 8;                              // channels per workgroup of the tile transforms
 constexpr int RS = T + 1;                          // padded row stride of the real tile in LDS
 // per-channel plane strides.  The spectral <-> global copies run lanes over the 8 channels first (a 64-byte segment of
 // X^[f][m][c]): with the natural strides (544 complex = 1088 dwords, 1056 floats) all channels of a bin fall on ONE bank - PMC:
@@ -83,17 +81,15 @@ constexpr int RP = T * RS + 4;                     // floats per channel plane o
 // ---- x -> X^ ------------------------------------------------------------------------------------------------------------
 // grid (Cp / 8, tiles of this tensor); window origin = (V*a + org, V*b + org); `valid` = 32 for halo windows (org = -4),
 // 24 for the zero-padded gradient tiles of the weight gradient (org = 0)
-template <int CG>
-__global__ __launch_bounds__(32 * CG, CG == 16 ? 4 : 1) void spec_fft_tiles_kernel(const float* __restrict__ in, int cs, int H, int W, int tiles_y, int tiles_x,
+__global__ __launch_bounds__(256) void spec_fft_tiles_kernel(const float* __restrict__ in, int cs, int H, int W, int tiles_y, int tiles_x,
                                                              int org, int valid, float2* __restrict__ out, int m0, int Mtot, int Cp, int ntiles, int ncg)
 {
     // the real tile R and the half-complex tile Cx share one buffer (static LDS is limited to 64 KB): a row is pulled into
     // registers, and only after a barrier written back as its spectrum
-    extern __shared__ __attribute__((aligned(16))) float2 buf[];     // [CG * PS]
-    constexpr int NTHR = 32 * CG, QN = CG / 4;
-    float* R = (float*)buf;                        // [CG][RP] floats: rows of RS  (33.9 KB of the 35.1 KB at CG = 8)
+    __shared__ float2 buf[CG * PS];
+    float* R = (float*)buf;                        // [CG][RP] floats: rows of RS  (33.9 KB of the 35.1 KB)
     float2* Cx = buf;                              // [CG][PS] complex: rows of KX
-    static_assert(RP * 4 <= PS * 8, "R must fit inside Cx");
+    static_assert(CG * RP * 4 <= CG * PS * 8, "R must fit inside Cx");
     // workgroup id -> (tile, channel group), XCD-aware: consecutive ids go round-robin over the 8 XCDs (each with its own L2), so
     // the channel groups of ONE tile - which share its 128-byte cache lines - take ids 8 apart: same XCD, back to back in time
     const int tid = threadIdx.x;
@@ -101,8 +97,8 @@ __global__ __launch_bounds__(32 * CG, CG == 16 ? 4 : 1) void spec_fft_tiles_kern
     if (mloc >= ntiles) return;
     const int b = mloc % tiles_x, a = (mloc / tiles_x) % tiles_y, n = mloc / (tiles_x * tiles_y);
     const int oy = V * a + org, ox = V * b + org;
-    for (int idx = tid; idx < T * T * QN; idx += NTHR) {
-        const int q = idx % QN, px = idx / QN, y = px >> 5, x = px & 31;
+    for (int idx = tid; idx < T * T * (CG / 4); idx += 256) {
+        const int q = idx & 1, px = idx >> 1, y = px >> 5, x = px & 31;
         const int gy = oy + y, gx = ox + x;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (y < valid && x < valid && gy >= 0 && gy < H && gx >= 0 && gx < W && c0 + 4 * q < cs)
@@ -133,20 +129,18 @@ __global__ __launch_bounds__(32 * CG, CG == 16 ? 4 : 1) void spec_fft_tiles_kern
     }
     __syncthreads();
     const size_t m = (size_t)m0 + mloc;
-    for (int idx = tid; idx < NF * CG; idx += NTHR) {
-        const int c = idx & (CG - 1), f = idx / CG;
+    for (int idx = tid; idx < NF * CG; idx += 256) {
+        const int c = idx & (CG - 1), f = idx >> 3;
         out[(m * NF + f) * Cp + c0 + c] = Cx[c * PS + f];               // f = ky * KX + kx is the in-plane offset
     }
 }
 
 // ---- Y^ -> y ------------------------------------------------------------------------------------------------------------
 // grid (ceil(cs / 8), tiles); writes the 24 x 24 valid block of tile m: out = (accumulate ? out : 0) + y + bias
-template <int CG>
-__global__ __launch_bounds__(32 * CG, CG == 16 ? 4 : 1) void spec_ifft_out_kernel(const float2* __restrict__ Yf, int m0, int Mtot, int Np, int H, int W, int tiles_y, int tiles_x,
+__global__ __launch_bounds__(256) void spec_ifft_out_kernel(const float2* __restrict__ Yf, int m0, int Mtot, int Np, int H, int W, int tiles_y, int tiles_x,
                                                             float* __restrict__ out, int cs, int Cout, const float* __restrict__ bias, int accumulate, int ntiles, int ncg)
 {
-    extern __shared__ __attribute__((aligned(16))) float2 buf[];     // [CG * PS]: Cx, then (after a barrier) the real tile R: see spec_fft_tiles_kernel
-    constexpr int NTHR = 32 * CG, QN = CG / 4;
+    __shared__ float2 buf[CG * PS];                // Cx, then (after a barrier) the real tile R: see spec_fft_tiles_kernel
     float* R = (float*)buf;
     float2* Cx = buf;
     const int tid = threadIdx.x;           // (tile, channel group) from the workgroup id as in spec_fft_tiles_kernel
@@ -154,8 +148,8 @@ __global__ __launch_bounds__(32 * CG, CG == 16 ? 4 : 1) void spec_ifft_out_kerne
     if (mloc >= ntiles) return;
     const int b = mloc % tiles_x, a = (mloc / tiles_x) % tiles_y, n = mloc / (tiles_x * tiles_y);
     const size_t m = (size_t)m0 + mloc;
-    for (int idx = tid; idx < NF * CG; idx += NTHR) {
-        const int c = idx & (CG - 1), f = idx / CG;
+    for (int idx = tid; idx < NF * CG; idx += 256) {
+        const int c = idx & (CG - 1), f = idx >> 3;
         Cx[c * PS + f] = (c0 + c < Np) ? Yf[(m * NF + f) * Np + c0 + c] : make_float2(0.f, 0.f);
     }
     __syncthreads();
@@ -184,8 +178,8 @@ __global__ __launch_bounds__(32 * CG, CG == 16 ? 4 : 1) void spec_ifft_out_kerne
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < V * V * QN; idx += NTHR) {
-        const int q = idx % QN, px = idx / QN, y = px / V, x = px - y * V;
+    for (int idx = tid; idx < V * V * (CG / 4); idx += 256) {
+        const int q = idx & 1, px = idx >> 1, y = px / V, x = px - y * V;
         const int gy = V * a + y, gx = V * b + x, c = c0 + 4 * q;
         if (gy >= H || gx >= W || c >= cs) continue;
         float* o = out + (((size_t)n * H + gy) * W + gx) * cs + c;
@@ -521,14 +515,9 @@ int ssie_spec_tiles(int H, int W, int* tiles_y, int* tiles_x)
 int ssie_launch_spec_fft(const float* in, int cs, int Cp, int N, int H, int W, int halo, float2* out, int m0, int Mtot, hipStream_t st)
 {
     int ty, tx; const int per = ssie_spec_tiles(H, W, &ty, &tx);
-    if (Cp % 8 || cs % 4) return 91;
-    const int cg = Cp % 16 == 0 ? 16 : 8;
-    const int ntiles = N * per, ncg = Cp / cg;
-    const dim3 grid((unsigned)((ntiles + 7) / 8 * 8 * ncg));
-    if (cg == 16) {
-        static unsigned seen = 0; ssie_allow_full_lds((const void*)spec_fft_tiles_kernel<16>, seen);
-        hipLaunchKernelGGL(spec_fft_tiles_kernel<16>, grid, dim3(512), (size_t)16 * PS * 8, st, in, cs, H, W, ty, tx, halo ? -4 : 0, halo ? T : V, out, m0, Mtot, Cp, ntiles, ncg);
-    } else hipLaunchKernelGGL(spec_fft_tiles_kernel<8>, grid, dim3(256), (size_t)8 * PS * 8, st, in, cs, H, W, ty, tx, halo ? -4 : 0, halo ? T : V, out, m0, Mtot, Cp, ntiles, ncg);
+    if (Cp % CG || cs % 4) return 91;
+    const int ntiles = N * per, ncg = Cp / CG;
+    hipLaunchKernelGGL(spec_fft_tiles_kernel, dim3((unsigned)((ntiles + 7) / 8 * 8 * ncg)), dim3(256), 0, st, in, cs, H, W, ty, tx, halo ? -4 : 0, halo ? T : V, out, m0, Mtot, Cp, ntiles, ncg);
     return hipGetLastError() == hipSuccess ? 0 : 92;
 }
 
@@ -537,13 +526,8 @@ int ssie_launch_spec_ifft(const float2* Yf, int m0, int Mtot, int Np, int N, int
 {
     int ty, tx; const int per = ssie_spec_tiles(H, W, &ty, &tx);
     if (cs % 4) return 93;
-    const int cg = cs % 16 == 0 ? 16 : 8;
-    const int ntiles = N * per, ncg = (cs + cg - 1) / cg;
-    const dim3 grid((unsigned)((ntiles + 7) / 8 * 8 * ncg));
-    if (cg == 16) {
-        static unsigned seen = 0; ssie_allow_full_lds((const void*)spec_ifft_out_kernel<16>, seen);
-        hipLaunchKernelGGL(spec_ifft_out_kernel<16>, grid, dim3(512), (size_t)16 * PS * 8, st, Yf, m0, Mtot, Np, H, W, ty, tx, out, cs, Cout, bias, accumulate, ntiles, ncg);
-    } else hipLaunchKernelGGL(spec_ifft_out_kernel<8>, grid, dim3(256), (size_t)8 * PS * 8, st, Yf, m0, Mtot, Np, H, W, ty, tx, out, cs, Cout, bias, accumulate, ntiles, ncg);
+    const int ntiles = N * per, ncg = (cs + CG - 1) / CG;
+    hipLaunchKernelGGL(spec_ifft_out_kernel, dim3((unsigned)((ntiles + 7) / 8 * 8 * ncg)), dim3(256), 0, st, Yf, m0, Mtot, Np, H, W, ty, tx, out, cs, Cout, bias, accumulate, ntiles, ncg);
     return hipGetLastError() == hipSuccess ? 0 : 94;
 }
 
