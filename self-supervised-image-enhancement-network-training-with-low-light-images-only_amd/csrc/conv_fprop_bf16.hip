@@ -79,6 +79,19 @@ __device__ __forceinline__ f32x4 ssie_unpack4bf(uint2 u)
     return r;
 }
 
+// 16-byte stores from the transposed accumulator layout: lane (li, h) holds channels 8g + 4h + {0..3} of its position for the four
+// groups g of a 32-channel accumulator tile, its partner lane (li, h ^ 1) the other four of every group.  v_permlane32_swap
+// exchanges the upper 32 lanes of one register with the lower 32 of another: for a group pair (g0, g0 + 1), X = packed g0 and
+// Y = packed g0 + 1, after the swap the lower half-wave holds (own X, partner's X) = channels 8 g0 .. 8 g0 + 7 and the upper one
+// (partner's Y, own Y) = channels 8 (g0 + 1) .. + 7 - both as (X, Y).  One dwordx4 store per pair instead of two dwordx2: the
+// epilogue is store-ISSUE bound (MI355X_MICROARCH.md, T21).
+__device__ __forceinline__ uint4 ssie_pair_swap(uint2 x, uint2 y)
+{
+    const auto a = __builtin_amdgcn_permlane32_swap(x.x, y.x, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(x.y, y.y, false, false);
+    return make_uint4(a[0], b[0], a[1], b[1]);
+}
+
 // one 32 x 32 accumulator tile -> memory, TRANSPOSED layout (the MFMAs are issued as D^T = W x X; see ssie_epilogue_t in
 // conv_device.h): lane (li, h) = output position li of the 2 x 16 M-tile, register r = channel 8*(r>>2) + 4h + (r&3).  Four
 // groups of four consecutive channels per lane: bf16 tensors move 8 bytes per group, fp32 outputs 16.
@@ -124,6 +137,17 @@ __device__ __forceinline__ void ssie_epilogue_ht(const ConvParams& p, const floa
         for (int g = 0; g < 4; ++g) a[g] = full[g] ? *(const uint2*)(ap + 8 * g) : make_uint2(0u, 0u);
 #pragma unroll
         for (int g = 0; g < 4; ++g) v[g] += ssie_unpack4bf(a[g]);
+    }
+    if (p.out_bf16 && (p.Cout & 7) == 0) {
+        // whole 8-channel groups: 16-byte stores (ssie_pair_swap; both lanes of a pair share pos_ok, so both are here)
+        const int hh = (c0 >> 2) & 1, cb = c0 - 4 * hh;
+        unsigned short* ob = (unsigned short*)p.out + opix + cb + 8 * hh;
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+            const uint4 u = ssie_pair_swap(ssie_pack4bf(v[g]), ssie_pack4bf(v[g + 1]));
+            if (SSIE_X_KEEP(cb + 8 * (g + hh) + 8 <= p.Cout, v[g][0])) *(uint4*)(ob + 8 * g) = u;
+        }
+        return;
     }
     if (p.out_bf16) {
         unsigned short* ob = (unsigned short*)p.out + opix + c0;
@@ -354,7 +378,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16_kernel(const ConvParam
 // 64-position x 64-channel register tile (4 accumulators) so one (tap, half chunk) costs 4 ds_read_b128 per 4 MFMAs instead of
 // 3 per 2 - the bf16 MFMA drains operands 16x faster than the fp32 one and the kernel is LDS-bandwidth-bound - and a step
 // moves 76 KB of DMA for twice the FLOPs of the 16 x 16 tile's 57.6 KB.  A-fragment addresses are tile-invariant and precomputed.
-template <int NA2, bool SINGLE>
+template <int NA2, bool SINGLE, bool ILV>
 __global__ __launch_bounds__(512, 2) void conv_fprop_bf16w_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -370,7 +394,8 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16w_kernel(const ConvPara
     float* bias_s = (float*)(s_next + 4);          // [Cout_pad]: the bias vector, staged once (see ssie_epilogue_ht)
     float* zero_bias_s = bias_s + p.Cout_pad;      // [Cout_pad] zeros: edge tiles of the lean path (bias already in the accumulators)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform: DMA piece indices and LDS destinations stay scalar
     const int h = lane >> 5, li = lane & 31;
 
     for (int t = tid; t < p.ntaps; t += NTHR)
@@ -479,7 +504,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16w_kernel(const ConvPara
     int lane_off[MT];                                   // element offset of (this lane's pixel of M-tile m, channel 4h) inside a tile
 #pragma unroll
     for (int m = 0; m < MT; ++m)
-        lane_off[m] = ((2 * wave + (li >> 4)) * p.so * p.Wout + (16 * m + (li & 15)) * p.so) * p.out_cstride + 4 * h;
+        lane_off[m] = ((2 * wave + (li >> 4)) * p.so * p.Wout + (16 * m + (li & 15)) * p.so) * p.out_cstride + 8 * h;   // 16-byte stores: ssie_pair_swap
 
     while (tile < total_tiles) {
         f32x16 acc[MT][NT];
@@ -534,7 +559,43 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16w_kernel(const ConvPara
                 if (more) HW_PREFETCH(nchunk, ng, n, a0, b0, co0, buf ^ 1, a_nxt)                         \
                 else if (ntile < total_tiles) HW_PREFETCH(0, 0, nn, na0, nb0, nco0, buf ^ 1, a_nxt)       \
             }
-            HW_ISSUE_NEXT
+            // ILV (9-tap layers): the next step's DMA is issued PIECE BY PIECE between the taps of this step's MFMA loop - one halo
+            // slot after each of taps 0-4, the (up to five) weight pieces after taps 5-7 - instead of as one block right behind
+            // the barrier.  An LDS-DMA instruction holds its wave at issue for several hundred cycles when the wave's previous ones
+            // are still in flight (stamps: 340 cycles per piece with eight waves issuing ten each back to back, 550 with four
+            // waves issuing nineteen), and an in-order wave has its MFMAs queued up behind; one piece per ~8 MFMAs finds the
+            // queue empty.
+            // Only steps whose halo tile lies inside the image take this path (one uniform base + a per-lane offset per slot); border
+            // tiles and up-sampled sources issue the block up front as before.
+            const bool pf_any = more || ntile < total_tiles;
+            const int pchunk = more ? nchunk : 0;
+            const int pn = more ? n : nn, pa0 = more ? a0 : na0, pb0 = more ? b0 : nb0, pco0 = more ? co0 : nco0;
+            const SrcSel ps = SINGLE ? ssie_only_src(p) : ssie_pick_src(p, pchunk * CKH);
+            const int pvy0 = pa0 + p.min_dy, pvx0 = pb0 + p.min_dx;
+            const bool ilv_now = ILV && tg == 9 && NA2 == 5 && pf_any && ps.sy == 1.f && ps.sx == 1.f && (ps.C & 31) == 0 &&
+                                 pvy0 >= 0 && pvx0 >= 0 && pvy0 + p.hp_h <= p.Hv && pvx0 + p.hp_w <= p.Wv;
+            f32x4* const pabuf = As0 + a_nxt * HP4;
+            const unsigned short* const psb = (const unsigned short*)ps.ptr +
+                ((long)(pn * ps.Hs + pvy0) * ps.Ws + pvx0) * ps.cstride + ps.coff + pchunk * CKH - ps.cbeg;
+            const f32x4* const pwsrc = (const f32x4*)p.wpacked + ((size_t)(pchunk * p.ntaps) * 4) * p.Cout_pad + pco0;
+            f32x4* const pbbuf = Bs0 + (buf ^ 1) * BSZ;
+#define HW_HALO_PIECE(I_)                                                                                 \
+            if (tid + (I_) * NTHR < HP4) {                                                                \
+                const int lo_ = (ahy[I_] * ps.Ws + ahx[I_]) * ps.cstride + 8 * aj[I_];                    \
+                GLDS16(psb + lo_, pabuf + (I_) * NTHR + wave * 64);                                       \
+            }
+#define HW_W_PIECE(J_)                                                                                    \
+            { const int q_ = wave + NW * (J_); if (q_ < 36) GLDS16(pwsrc + (size_t)q_ * p.Cout_pad + lane, pbbuf + q_ * 64); }
+#define HW_ILV_HOOK(TL_)                                                                                  \
+            if (ilv_now) {                                                                                \
+                if ((TL_) == 0) { HW_HALO_PIECE(0) } else if ((TL_) == 1) { HW_HALO_PIECE(1) }             \
+                else if ((TL_) == 2) { HW_HALO_PIECE(2) } else if ((TL_) == 3) { HW_HALO_PIECE(3) }        \
+                else if ((TL_) == 4) { HW_HALO_PIECE(4) }                                                 \
+                else if ((TL_) == 5) { HW_W_PIECE(0) HW_W_PIECE(1) }                                      \
+                else if ((TL_) == 6) { HW_W_PIECE(2) HW_W_PIECE(3) }                                      \
+                else if ((TL_) == 7) { HW_W_PIECE(4) }                                                    \
+            }
+            if (!ilv_now) HW_ISSUE_NEXT
             HT_ACC(4);
 
             const char* Ab = (const char*)(As0 + a_cur * HP4);
@@ -559,6 +620,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16w_kernel(const ConvPara
                     W_LD(bY, aY, tl, 1)                                                                   \
                     W_MFMA(bX, aX)                                                                        \
                     if (tl + 1 < TG_) W_LD(bX, aX, (tl + 1 < TG_ ? tl + 1 : 0), 0)                         \
+                    if (TG_ == 9) HW_ILV_HOOK(tl)                                                         \
                     W_MFMA(bY, aY)                                                                        \
                 }                                                                                         \
             }
@@ -584,6 +646,9 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16w_kernel(const ConvPara
 #undef W_LD
 #undef W_MFMA
 #undef HW_ISSUE_NEXT
+#undef HW_ILV_HOOK
+#undef HW_W_PIECE
+#undef HW_HALO_PIECE
             // draw the tile after next from the queue; its value is only needed at the next step's hand-off
             if (tid == 0 && step == 0 && nsteps > 1 && p.tile_counter)
                 fetched = (int)gridDim.x + atomicAdd(p.tile_counter, 1);
@@ -602,11 +667,15 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16w_kernel(const ConvPara
 #pragma unroll
                 for (int c = 0; c < NT; ++c)
 #pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
+                    for (int g2 = 0; g2 < 4; g2 += 2) {
                         const f32x16& a = acc[m][c];
-                        const uint2 u = make_uint2(ssie_pack2bf(fmaxf(a[4 * g4], relu_lo), fmaxf(a[4 * g4 + 1], relu_lo)),
-                                                   ssie_pack2bf(fmaxf(a[4 * g4 + 2], relu_lo), fmaxf(a[4 * g4 + 3], relu_lo)));
-                        if (SSIE_X_KEEP(true, a[0])) *(uint2*)(tbase + lane_off[m] + 32 * c + 8 * g4) = u;
+                        uint2 u[2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e)
+                            u[e] = make_uint2(ssie_pack2bf(fmaxf(a[4 * (g2 + e)], relu_lo), fmaxf(a[4 * (g2 + e) + 1], relu_lo)),
+                                              ssie_pack2bf(fmaxf(a[4 * (g2 + e) + 2], relu_lo), fmaxf(a[4 * (g2 + e) + 3], relu_lo)));
+                        const uint4 v = ssie_pair_swap(u[0], u[1]);
+                        if (SSIE_X_KEEP(true, a[0])) *(uint4*)(tbase + lane_off[m] + 32 * c + 8 * g2) = v;
                     }
         } else {
 #pragma unroll
@@ -628,9 +697,259 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16w_kernel(const ConvPara
 }
 
 
+// Wave-specialised form of the wide kernel (the shipped one for the 16 x 32 geometry): 12 waves per workgroup, three per SIMD.
+//   waves 0-7  CONSUMERS: fragment reads, MFMAs and the epilogue - no global loads at all
+//   waves 8-11 PRODUCERS: the LDS-DMA of the next step's halo tile and weight group (address arithmetic + 19-20
+//              global_load_lds per wave and step), then s_waitcnt vmcnt(0)
+// and ONE s_barrier per step that all twelve waves pass: it tells the consumers that the step's operands have landed and the
+// producers that the other buffer has been read.  In the eight-wave kernel every wave issued its share of the DMA between the
+// barrier and its tap loop; stamps (profiles/r02_bf16_stamps.md) put that phase at 6 800 of a tile's 29 500 cycles - the waves
+// sit in the vector-memory issue queue (76 KB per step against ~22 B/clk) with their MFMAs queued up behind - and another 6 500
+// in the barrier that follows a step that is shorter than the DMA's flight.  A stalled producer holds up nobody's MFMAs.
+// Static tile assignment (tile += gridDim.x), one tap group per chunk (<= 9 taps), so a step = one 32-channel chunk.
+template <int TGT, bool SINGLE, int NWC>
+__global__ __launch_bounds__(64 * (NWC + 4)) void conv_fprop_bf16ws_kernel(const ConvParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    constexpr int NT = 2, NWP = 4, BN = 64, TH = 16, TWW = 32, CKH = 32;
+    constexpr int RW = TH / NWC, MT = RW;           // a consumer wave owns RW tile rows = MT M-tiles of 2 rows x 16 columns
+    constexpr int PTHR = 64 * NWP, NTHR = 64 * (NWC + NWP);
+    constexpr int NAP = 10;                         // DMA rounds of the 256 producer lanes over the 18 x 34 x 4 halo slots
+    constexpr int BSZ = SSIE_TG * 4 * BN;           // float4 per B buffer
+    const int HP = p.hp_h * p.hp_w, HP4 = HP * 4;
+    f32x4* As0 = (f32x4*)smem_f;                    // [2][HP4]
+    f32x4* Bs0 = As0 + 2 * HP4;                     // [2][BSZ]
+    float* bias_s = (float*)(Bs0 + 2 * BSZ) + SSIE_MAX_TAPS + 4;   // [Cout_pad] (same LDS map as the eight-wave kernel)
+    float* zero_bias_s = bias_s + p.Cout_pad;
 
-template __global__ void conv_fprop_bf16w_kernel<5, false>(const ConvParams);
-template __global__ void conv_fprop_bf16w_kernel<5, true>(const ConvParams);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, li = lane & 31;
+    for (int t = tid; t < p.Cout_pad; t += NTHR) { bias_s[t] = (p.bias && t < p.Cout) ? p.bias[t] : 0.f; zero_bias_s[t] = 0.f; }
+
+    __syncthreads();                                // bias_s is read at the top of a tile, before that tile's first step barrier
+
+    const int nsteps = p.nchunks;
+    const int total_tiles = p.N * p.tiles_y * p.tiles_x * p.co_blocks;
+    int tile = blockIdx.x;
+    if (tile >= total_tiles) return;
+#define WS_DECODE(T, N_, A0_, B0_, CO0_)                                                  \
+    {                                                                                     \
+        int q_ = (T);                                                                     \
+        CO0_ = (q_ % p.co_blocks) * BN; q_ /= p.co_blocks;                                \
+        B0_ = (q_ % p.tiles_x) * TWW; q_ /= p.tiles_x;                                    \
+        A0_ = (q_ % p.tiles_y) * TH; N_ = q_ / p.tiles_y;                                 \
+    }
+    int n, a0, b0, co0;
+    WS_DECODE(tile, n, a0, b0, co0)
+
+    if (wave >= NWC) {
+        // ------------------------------------------------ producers ------------------------------------------------
+        const int ptid = tid - 64 * NWC, pwave = wave - NWC;
+        // this lane's halo slots: LDS slot id = i*PTHR + ptid (linear), it holds channel octet j = (id&3) ^ swz(pixel)
+        int ahy[NAP], ahx[NAP], aj[NAP];
+#pragma unroll
+        for (int i = 0; i < NAP; ++i) {
+            const int id = min(ptid + i * PTHR, HP4 - 1);
+            const int pix = id >> 2;
+            ahy[i] = pix / p.hp_w; ahx[i] = pix - ahy[i] * p.hp_w; aj[i] = (id & 3) ^ ssie_swz(pix);
+        }
+#define WS_PREFETCH(CHUNK, N_, A0_, B0_, CO0_, BUF)                                                           \
+        {                                                                                                     \
+            const SrcSel s_ = SINGLE ? ssie_only_src(p) : ssie_pick_src(p, (CHUNK) * CKH);                    \
+            const bool up_ = s_.sy != 1.f || s_.sx != 1.f;                                                    \
+            const int vy0_ = (A0_) + p.min_dy, vx0_ = (B0_) + p.min_dx;                                       \
+            f32x4* abuf_ = As0 + (BUF) * HP4;                                                                 \
+            const bool lean_ = !up_ && (s_.C & 31) == 0 && vy0_ >= 0 && vx0_ >= 0 && vy0_ + p.hp_h <= p.Hv && vx0_ + p.hp_w <= p.Wv; \
+            if (lean_) {                                                                                      \
+                const unsigned short* sb_ = (const unsigned short*)s_.ptr +                                   \
+                    ((size_t)((N_) * s_.Hs + vy0_) * s_.Ws + vx0_) * s_.cstride + s_.coff + (CHUNK) * CKH - s_.cbeg; \
+                _Pragma("unroll") for (int i_ = 0; i_ < NAP; ++i_) {                                          \
+                    if (ptid + i_ * PTHR < HP4) {                                                             \
+                        const int lo_ = (ahy[i_] * s_.Ws + ahx[i_]) * s_.cstride + 8 * aj[i_];               \
+                        GLDS16(sb_ + lo_, abuf_ + i_ * PTHR + pwave * 64);                                    \
+                    }                                                                                         \
+                }                                                                                             \
+            } else {                                                                                          \
+                _Pragma("unroll") for (int i_ = 0; i_ < NAP; ++i_) {                                          \
+                    if (ptid + i_ * PTHR < HP4) {                                                             \
+                        const f32x4* g_ = ssie_virtual_addr_h(s_, up_, (N_), vy0_ + ahy[i_], vx0_ + ahx[i_], p.Hv, p.Wv, \
+                                                              (CHUNK) * CKH + 8 * aj[i_] - s_.cbeg);          \
+                        GLDS16(g_, abuf_ + i_ * PTHR + pwave * 64);                                           \
+                    }                                                                                         \
+                }                                                                                             \
+            }                                                                                                 \
+            const f32x4* wsrc_ = (const f32x4*)p.wpacked + ((size_t)((CHUNK) * p.ntaps) * 4) * p.Cout_pad + (CO0_); \
+            f32x4* bbuf_ = Bs0 + (BUF) * BSZ;                                                                 \
+            for (int q_ = pwave; q_ < p.ntaps * 4; q_ += NWP)           /* rows of BN = 64 slots: one piece each */ \
+                GLDS16(wsrc_ + (size_t)q_ * p.Cout_pad + lane, bbuf_ + q_ * 64);                              \
+        }
+        WS_PREFETCH(0, n, a0, b0, co0, 0)
+        int gstep = 0;
+        HT_DECL
+        while (tile < total_tiles) {
+            const int ntile = tile + (int)gridDim.x;
+            int nn = n, na0 = a0, nb0 = b0, nco0 = co0;
+            if (ntile < total_tiles) WS_DECODE(ntile, nn, na0, nb0, nco0)
+            for (int step = 0; step < nsteps; ++step, ++gstep) {
+                const int buf = gstep & 1;
+                // my share of this step's operands has landed; behind the barrier everybody's has, and the consumers are done
+                // with the other buffer
+                HT_ACC(4);
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                HT_ACC(10);
+                asm volatile("s_barrier" ::: "memory");
+                HT_ACC(11);
+                if (step + 1 < nsteps) WS_PREFETCH(step + 1, n, a0, b0, co0, buf ^ 1)
+                else if (ntile < total_tiles) WS_PREFETCH(0, nn, na0, nb0, nco0, buf ^ 1)
+            }
+            n = nn; a0 = na0; b0 = nb0; co0 = nco0; tile = ntile;
+        }
+#ifdef SSIE_STAMP
+        if (ssie_stamp_buf_h && tid == 64 * NWC) { ssie_stamp_buf_h[(size_t)blockIdx.x * 12 + 4] = st_[4]; ssie_stamp_buf_h[(size_t)blockIdx.x * 12 + 10] = st_[10]; ssie_stamp_buf_h[(size_t)blockIdx.x * 12 + 11] = st_[11]; }
+#endif
+#undef WS_PREFETCH
+        return;
+    }
+
+    // ---------------------------------------------------- consumers ----------------------------------------------------
+    int pixbase[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) pixbase[m] = (RW * wave + 2 * (m >> 1) + (li >> 4)) * p.hp_w + 16 * (m & 1) + (li & 15);
+    // byte offset inside a halo buffer of (M-tile m, tap t, k-quad 0); k-quad 1 is the same address ^ 32 (slot index ^ 2)
+    int aaddr[SSIE_TG][MT];
+#pragma unroll
+    for (int t = 0; t < SSIE_TG; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int hp = pixbase[m] + ((int)p.tap_dy[t] - p.min_dy) * p.hp_w + ((int)p.tap_dx[t] - p.min_dx);
+            aaddr[t][m] = t < p.ntaps ? (hp * 4 + (h ^ ssie_swz(hp))) * 16 : 0;
+        }
+    // lean epilogue only (see conv_fprop_bf16w_kernel; the launcher sends every other layer to that kernel)
+    const float relu_lo = p.act == ACT_RELU ? 0.f : -3.0e38f;
+    int lane_off[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+        lane_off[m] = ((RW * wave + 2 * (m >> 1) + (li >> 4)) * p.so * p.Wout + (16 * (m & 1) + (li & 15)) * p.so) * p.out_cstride + 8 * h;
+
+    int gstep = 0;
+    HT_DECL
+    while (tile < total_tiles) {
+        // the bias is the accumulators' initial value
+        f32x16 acc[MT][NT];
+        {
+            const float* bsrc = bias_s + co0 + 4 * h;
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 b = *(const f32x4*)(bsrc + 32 * c + 8 * g4);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[m][c][4 * g4 + j] = b[j];
+                }
+        }
+
+        for (int step = 0; step < nsteps; ++step, ++gstep) {
+            const int buf = gstep & 1;
+            // no vmcnt here: a consumer's only vector-memory traffic is its epilogue stores, which nobody waits for
+            HT_ACC(5);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            HT_ACC(step == 0 ? 1 : 2);
+            const char* Ab = (const char*)(As0 + buf * HP4);
+            const f32x4* Bl = Bs0 + buf * BSZ + h * BN + li;          // this lane's column of the weight group
+#define W_LD(BF, AF, TL, SC)                                                                              \
+            {                                                                                             \
+                _Pragma("unroll") for (int c_ = 0; c_ < NT; ++c_) BF[c_] = Bl[((TL) * 4 + (SC) * 2) * BN + c_ * 32]; \
+                _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_)                                         \
+                    AF[m_] = *(const f32x4*)(Ab + ((SC) ? (aaddr[TL][m_] ^ 32) : aaddr[TL][m_]));         \
+            }
+#define W_MFMA(BF, AF)                                                                                    \
+            _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_)                                             \
+            _Pragma("unroll") for (int c_ = 0; c_ < NT; ++c_) acc[m_][c_] = MFMA_BF16(BF[c_], AF[m_], acc[m_][c_]);
+#define W_TAPS(TG_)                                                                                       \
+            {                                                                                             \
+                f32x4 bX[NT], bY[NT], aX[MT], aY[MT];                                                     \
+                W_LD(bX, aX, 0, 0)                                                                        \
+                _Pragma("unroll") for (int tl = 0; tl < TG_; ++tl) {                                      \
+                    W_LD(bY, aY, tl, 1)                                                                   \
+                    W_MFMA(bX, aX)                                                                        \
+                    if (tl + 1 < TG_) W_LD(bX, aX, (tl + 1 < TG_ ? tl + 1 : 0), 0)                         \
+                    W_MFMA(bY, aY)                                                                        \
+                }                                                                                         \
+            }
+            W_TAPS(TGT)
+#undef W_TAPS
+#undef W_LD
+#undef W_MFMA
+            HT_ACC(7);
+        }
+
+        const bool inside = a0 + TH <= p.Ho && b0 + TWW <= p.Wo && (a0 + TH - 1) * p.so + p.py < p.Hout && (b0 + TWW - 1) * p.so + p.px < p.Wout;
+        if (inside) {
+            unsigned short* tbase = (unsigned short*)p.out + ((size_t)(n * p.Hout + a0 * p.so + p.py) * p.Wout + b0 * p.so + p.px) * p.out_cstride + p.out_coff + co0;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int c = 0; c < NT; ++c)
+#pragma unroll
+                    for (int g2 = 0; g2 < 4; g2 += 2) {
+                        const f32x16& a = acc[m][c];
+                        uint2 u[2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e)
+                            u[e] = make_uint2(ssie_pack2bf(fmaxf(a[4 * (g2 + e)], relu_lo), fmaxf(a[4 * (g2 + e) + 1], relu_lo)),
+                                              ssie_pack2bf(fmaxf(a[4 * (g2 + e) + 2], relu_lo), fmaxf(a[4 * (g2 + e) + 3], relu_lo)));
+                        *(uint4*)(tbase + lane_off[m] + 32 * c + 8 * g2) = ssie_pair_swap(u[0], u[1]);
+                    }
+        } else {                                    // edge tile: the same stores, per-position validity
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                bool ok;
+                const size_t opix = ssie_epilogue_pos(p, n, a0 + RW * wave + 2 * (m >> 1), b0 + 16 * (m & 1), li, ok);
+                unsigned short* ob = (unsigned short*)p.out + opix + co0 + 8 * h;
+#pragma unroll
+                for (int c = 0; c < NT; ++c)
+#pragma unroll
+                    for (int g2 = 0; g2 < 4; g2 += 2) {
+                        const f32x16& a = acc[m][c];
+                        uint2 u[2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e)
+                            u[e] = make_uint2(ssie_pack2bf(fmaxf(a[4 * (g2 + e)], relu_lo), fmaxf(a[4 * (g2 + e) + 1], relu_lo)),
+                                              ssie_pack2bf(fmaxf(a[4 * (g2 + e) + 2], relu_lo), fmaxf(a[4 * (g2 + e) + 3], relu_lo)));
+                        const uint4 v = ssie_pair_swap(u[0], u[1]);         // (every lane takes part in the swap: no branch around it)
+                        if (ok) *(uint4*)(ob + 32 * c + 8 * g2) = v;
+                    }
+            }
+        }
+        HT_ACC(9);
+        HT_TILE;
+        tile += (int)gridDim.x;
+        if (tile < total_tiles) WS_DECODE(tile, n, a0, b0, co0)
+    }
+#ifdef SSIE_STAMP
+    st_[3] = __builtin_amdgcn_s_memtime();
+    if (ssie_stamp_buf_h && tid == 0)
+        for (int k_ = 0; k_ < 10; ++k_) if (k_ != 4) ssie_stamp_buf_h[(size_t)blockIdx.x * 12 + k_] = st_[k_];
+#endif
+#undef WS_DECODE
+}
+
+template __global__ void conv_fprop_bf16ws_kernel<9, false, 8>(const ConvParams);
+template __global__ void conv_fprop_bf16ws_kernel<9, true, 8>(const ConvParams);
+template __global__ void conv_fprop_bf16ws_kernel<1, false, 8>(const ConvParams);
+template __global__ void conv_fprop_bf16ws_kernel<1, true, 8>(const ConvParams);
+template __global__ void conv_fprop_bf16ws_kernel<9, false, 4>(const ConvParams);
+template __global__ void conv_fprop_bf16ws_kernel<9, true, 4>(const ConvParams);
+
+
+
+template __global__ void conv_fprop_bf16w_kernel<5, false, false>(const ConvParams);
+template __global__ void conv_fprop_bf16w_kernel<5, true, false>(const ConvParams);
+template __global__ void conv_fprop_bf16w_kernel<5, false, true>(const ConvParams);
+template __global__ void conv_fprop_bf16w_kernel<5, true, true>(const ConvParams);
 
 #define INST_H(NT, NA2, TH) template __global__ void conv_fprop_bf16_kernel<NT, NA2, TH>(const ConvParams);
 INST_H(2, 3, 16) INST_H(2, 5, 16) INST_H(1, 3, 16) INST_H(1, 5, 16) INST_H(2, 5, 8)
@@ -653,6 +972,8 @@ static int launch_h_t(const ConvParams& p, size_t lds, hipStream_t st)
 
 // p must come from ssie_make_conv_bf16 (th = 16 for stride 1, 8 for stride 2; 32-channel chunks)
 int ssie_bf16_dynamic_queue = 0;      // see below
+int ssie_bf16_ws = 3;                 // 16 x 32 geometry: 0 = eight-wave kernel, 1 = wave-specialised 8 consumers + 4 producers, 2 = eight-wave kernel with the DMA interleaved between the taps (measured slower), 3 = wave-specialised 4 consumers (64 positions x 64 channels x 2 each) + 4 producers for the 9-tap layers
+extern "C" void ssie_debug_set_bf16_ws(int v) { ssie_bf16_ws = v; }
 int ssie_launch_fprop_bf16(const ConvParams& p_in, hipStream_t st)
 {
     // Static tile assignment (tile += gridDim.x).  The dynamic queue of the fp32 kernels draws every tile with a returning
@@ -665,17 +986,42 @@ int ssie_launch_fprop_bf16(const ConvParams& p_in, hipStream_t st)
     const size_t lds = lds_bytes_h(p, nt);
     if (na2 > 5 || lds > 160 * 1024) return 62;
     if (p.tw == 32) {                      // geometry built for the wide kernel (ssie_make_conv_bf16)
-        static unsigned seen_a = 0, seen_b = 0;
-        ssie_allow_full_lds((const void*)conv_fprop_bf16w_kernel<5, false>, seen_a);
-        ssie_allow_full_lds((const void*)conv_fprop_bf16w_kernel<5, true>, seen_b);
+        static unsigned seen_a = 0, seen_b = 0, seen_e = 0, seen_f = 0;
+        ssie_allow_full_lds((const void*)conv_fprop_bf16w_kernel<5, false, false>, seen_a);
+        ssie_allow_full_lds((const void*)conv_fprop_bf16w_kernel<5, true, false>, seen_b);
+        ssie_allow_full_lds((const void*)conv_fprop_bf16w_kernel<5, false, true>, seen_e);
+        ssie_allow_full_lds((const void*)conv_fprop_bf16w_kernel<5, true, true>, seen_f);
         const size_t tiles = (size_t)p.N * p.tiles_y * p.tiles_x * p.co_blocks;
         const dim3 grid((unsigned)(tiles < 256 ? tiles : 256));
 #ifdef SSIE_STAMP
         const bool stamp_this = g_stamp_host_buf && g_stamp_launch++ == g_stamp_target;
         if (stamp_this) { hipStreamSynchronize(st); hipMemcpyToSymbol(HIP_SYMBOL(ssie_stamp_buf_h), &g_stamp_host_buf, sizeof(void*)); }
 #endif
-        if (p.nsrc == 1) hipLaunchKernelGGL((conv_fprop_bf16w_kernel<5, true>), grid, dim3(512), lds, st, p);
-        else hipLaunchKernelGGL((conv_fprop_bf16w_kernel<5, false>), grid, dim3(512), lds, st, p);
+        // layers that end in the lean epilogue (bf16 output, ReLU or none, no residual / second output, whole 32-channel groups)
+        // with 9 taps or 1 run the wave-specialised kernel
+        const bool lean = p.out_bf16 && !p.addsrc && !p.out2 && (p.Cout % 32) == 0 && p.act != ACT_SIGMOID;
+        if (ssie_bf16_ws == 3 && lean && p.ntaps == 9 && p.hp_h * p.hp_w * 4 <= 2560 && !p.tile_counter) {
+            static unsigned seen_w4[2] = {0, 0};
+            ssie_allow_full_lds((const void*)conv_fprop_bf16ws_kernel<9, false, 4>, seen_w4[0]);
+            ssie_allow_full_lds((const void*)conv_fprop_bf16ws_kernel<9, true, 4>, seen_w4[1]);
+            if (p.nsrc == 1) hipLaunchKernelGGL((conv_fprop_bf16ws_kernel<9, true, 4>), grid, dim3(512), lds, st, p);
+            else hipLaunchKernelGGL((conv_fprop_bf16ws_kernel<9, false, 4>), grid, dim3(512), lds, st, p);
+        }
+        else if ((ssie_bf16_ws == 1 || ssie_bf16_ws == 3) && lean && (p.ntaps == 9 || p.ntaps == 1) && p.hp_h * p.hp_w * 4 <= 2560 && !p.tile_counter) {
+            static unsigned seen_ws[4] = {0, 0, 0, 0};
+            ssie_allow_full_lds((const void*)conv_fprop_bf16ws_kernel<9, false, 8>, seen_ws[0]);
+            ssie_allow_full_lds((const void*)conv_fprop_bf16ws_kernel<9, true, 8>, seen_ws[1]);
+            ssie_allow_full_lds((const void*)conv_fprop_bf16ws_kernel<1, false, 8>, seen_ws[2]);
+            ssie_allow_full_lds((const void*)conv_fprop_bf16ws_kernel<1, true, 8>, seen_ws[3]);
+            if (p.ntaps == 9 && p.nsrc == 1) hipLaunchKernelGGL((conv_fprop_bf16ws_kernel<9, true, 8>), grid, dim3(768), lds, st, p);
+            else if (p.ntaps == 9) hipLaunchKernelGGL((conv_fprop_bf16ws_kernel<9, false, 8>), grid, dim3(768), lds, st, p);
+            else if (p.nsrc == 1) hipLaunchKernelGGL((conv_fprop_bf16ws_kernel<1, true, 8>), grid, dim3(768), lds, st, p);
+            else hipLaunchKernelGGL((conv_fprop_bf16ws_kernel<1, false, 8>), grid, dim3(768), lds, st, p);
+        }
+        else if (ssie_bf16_ws == 2 && p.ntaps == 9 && p.nsrc == 1) hipLaunchKernelGGL((conv_fprop_bf16w_kernel<5, true, true>), grid, dim3(512), lds, st, p);
+        else if (ssie_bf16_ws == 2 && p.ntaps == 9) hipLaunchKernelGGL((conv_fprop_bf16w_kernel<5, false, true>), grid, dim3(512), lds, st, p);
+        else if (p.nsrc == 1) hipLaunchKernelGGL((conv_fprop_bf16w_kernel<5, true, false>), grid, dim3(512), lds, st, p);
+        else hipLaunchKernelGGL((conv_fprop_bf16w_kernel<5, false, false>), grid, dim3(512), lds, st, p);
 #ifdef SSIE_STAMP
         if (stamp_this) { hipStreamSynchronize(st); void* z = nullptr; hipMemcpyToSymbol(HIP_SYMBOL(ssie_stamp_buf_h), &z, sizeof(void*)); }
 #endif

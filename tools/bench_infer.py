@@ -48,7 +48,7 @@ def main():
     rows = [(ms[i], fl[i], H.Plan.KINDS[kinds[i]], names[i]) for i in range(nops)]
     tot = sum(r[0] for r in rows)
     print(f"forward op list: {nops} launches, {tot:.2f} ms")
-    for t, f, k, nm in sorted(rows, key=lambda r: -r[0])[:18]:
+    for t, f, k, nm in sorted(rows, key=lambda r: -r[0])[:int(os.environ.get("TOP", "18"))]:
         print(f"{t:8.3f} ms {100*t/tot:5.1f}%  {f/(t*1e-3)/1e12 if f else 0:6.1f} TF  {k:22s} {nm}")
 
 if __name__ == "__main__":

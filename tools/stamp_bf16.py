@@ -41,6 +41,11 @@ def main():
                   f"  start spread {s[:, 0].max() - s[:, 0].min():.0f}  end spread {s[:, 3].max() - s[:, 3].min():.0f}  first start -> last end {s[:, 3].max() - s[:, 0].min():.0f}")
             names = {1: "barrier wait, first step of tile", 2: "barrier wait, other steps", 4: "DMA issue", 7: "MFMA tap loops", 8: "end of MFMA loop -> epilogue", 9: "epilogue proper",
                      5: "after epilogue: bookkeeping, next tile's first step head"}
+            prod = {4: "producer: DMA issue", 10: "producer: wait for landing (vmcnt)", 11: "producer: barrier wait"}
+            if s[:, 10].sum() > 0:
+                for kx, nm in prod.items():
+                    print(f"  {nm:34s} {np.mean(s[:, kx] / nt):9.0f} cycles/tile")
+                names.pop(4)
             for kx, nm in names.items():
                 print(f"  {nm:34s} {np.mean(s[:, kx] / nt):9.0f} cycles/tile  {100 * s[:, kx].sum() / tot.sum():5.1f} %")
             acc = sum(s[:, kx] for kx in names)
