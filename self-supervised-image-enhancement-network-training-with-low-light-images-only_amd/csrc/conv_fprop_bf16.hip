@@ -707,7 +707,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16w_kernel(const ConvPara
 // sit in the vector-memory issue queue (76 KB per step against ~22 B/clk) with their MFMAs queued up behind - and another 6 500
 // in the barrier that follows a step that is shorter than the DMA's flight.  A stalled producer holds up nobody's MFMAs.
 // Static tile assignment (tile += gridDim.x), one tap group per chunk (<= 9 taps), so a step = one 32-channel chunk.
-template <int TGT, bool SINGLE, int NWC>
+template <int TGT, bool SINGLE, int NWC, bool RESW>
 __global__ __launch_bounds__(64 * (NWC + 4)) void conv_fprop_bf16ws_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -754,6 +754,13 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void conv_fprop_bf16ws_kernel(const
             const int pix = id >> 2;
             ahy[i] = pix / p.hp_w; ahx[i] = pix - ahy[i] * p.hp_w; aj[i] = (id & 3) ^ ssie_swz(pix);
         }
+#define WS_WEIGHTS(CHUNK, CO0_, BUF)                                                                          \
+        {                                                                                                     \
+            const f32x4* wsrc_ = (const f32x4*)p.wpacked + ((size_t)((CHUNK) * p.ntaps) * 4) * p.Cout_pad + (CO0_); \
+            f32x4* bbuf_ = Bs0 + (BUF) * BSZ;                                                                 \
+            for (int q_ = pwave; q_ < p.ntaps * 4; q_ += NWP)           /* rows of BN = 64 slots: one piece each */ \
+                GLDS16(wsrc_ + (size_t)q_ * p.Cout_pad + lane, bbuf_ + q_ * 64);                              \
+        }
 #define WS_PREFETCH(CHUNK, N_, A0_, B0_, CO0_, BUF)                                                           \
         {                                                                                                     \
             const SrcSel s_ = SINGLE ? ssie_only_src(p) : ssie_pick_src(p, (CHUNK) * CKH);                    \
@@ -779,11 +786,11 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void conv_fprop_bf16ws_kernel(const
                     }                                                                                         \
                 }                                                                                             \
             }                                                                                                 \
-            const f32x4* wsrc_ = (const f32x4*)p.wpacked + ((size_t)((CHUNK) * p.ntaps) * 4) * p.Cout_pad + (CO0_); \
-            f32x4* bbuf_ = Bs0 + (BUF) * BSZ;                                                                 \
-            for (int q_ = pwave; q_ < p.ntaps * 4; q_ += NWP)           /* rows of BN = 64 slots: one piece each */ \
-                GLDS16(wsrc_ + (size_t)q_ * p.Cout_pad + lane, bbuf_ + q_ * 64);                              \
+            if (!RESW) WS_WEIGHTS(CHUNK, CO0_, BUF)                                                           \
         }
+        // RESW (at most two chunks, one output-channel block): the layer's whole packed weight stays in LDS - chunk c in B
+        // buffer c - and a step moves only its halo tile: half the LDS-DMA pieces per tile
+        if (RESW) for (int c_ = 0; c_ < nsteps; ++c_) WS_WEIGHTS(c_, 0, c_)
         WS_PREFETCH(0, n, a0, b0, co0, 0)
         int gstep = 0;
         HT_DECL
@@ -809,6 +816,7 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void conv_fprop_bf16ws_kernel(const
         if (ssie_stamp_buf_h && tid == 64 * NWC) { ssie_stamp_buf_h[(size_t)blockIdx.x * 12 + 4] = st_[4]; ssie_stamp_buf_h[(size_t)blockIdx.x * 12 + 10] = st_[10]; ssie_stamp_buf_h[(size_t)blockIdx.x * 12 + 11] = st_[11]; }
 #endif
 #undef WS_PREFETCH
+#undef WS_WEIGHTS
         return;
     }
 
@@ -858,7 +866,7 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void conv_fprop_bf16ws_kernel(const
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             HT_ACC(step == 0 ? 1 : 2);
             const char* Ab = (const char*)(As0 + buf * HP4);
-            const f32x4* Bl = Bs0 + buf * BSZ + h * BN + li;          // this lane's column of the weight group
+            const f32x4* Bl = Bs0 + (RESW ? step : buf) * BSZ + h * BN + li;          // this lane's column of the weight group
 #define W_LD(BF, AF, TL, SC)                                                                              \
             {                                                                                             \
                 _Pragma("unroll") for (int c_ = 0; c_ < NT; ++c_) BF[c_] = Bl[((TL) * 4 + (SC) * 2) * BN + c_ * 32]; \
@@ -937,12 +945,14 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void conv_fprop_bf16ws_kernel(const
 #undef WS_DECODE
 }
 
-template __global__ void conv_fprop_bf16ws_kernel<9, false, 8>(const ConvParams);
-template __global__ void conv_fprop_bf16ws_kernel<9, true, 8>(const ConvParams);
-template __global__ void conv_fprop_bf16ws_kernel<1, false, 8>(const ConvParams);
-template __global__ void conv_fprop_bf16ws_kernel<1, true, 8>(const ConvParams);
-template __global__ void conv_fprop_bf16ws_kernel<9, false, 4>(const ConvParams);
-template __global__ void conv_fprop_bf16ws_kernel<9, true, 4>(const ConvParams);
+template __global__ void conv_fprop_bf16ws_kernel<9, false, 8, false>(const ConvParams);
+template __global__ void conv_fprop_bf16ws_kernel<9, true, 8, false>(const ConvParams);
+template __global__ void conv_fprop_bf16ws_kernel<1, false, 8, false>(const ConvParams);
+template __global__ void conv_fprop_bf16ws_kernel<1, true, 8, false>(const ConvParams);
+template __global__ void conv_fprop_bf16ws_kernel<9, false, 4, false>(const ConvParams);
+template __global__ void conv_fprop_bf16ws_kernel<9, true, 4, false>(const ConvParams);
+template __global__ void conv_fprop_bf16ws_kernel<9, true, 8, true>(const ConvParams);
+template __global__ void conv_fprop_bf16ws_kernel<9, true, 4, true>(const ConvParams);
 
 
 
@@ -974,6 +984,8 @@ static int launch_h_t(const ConvParams& p, size_t lds, hipStream_t st)
 int ssie_bf16_dynamic_queue = 0;      // see below
 int ssie_bf16_ws = 3;                 // 16 x 32 geometry: 0 = eight-wave kernel, 1 = wave-specialised 8 consumers + 4 producers, 2 = eight-wave kernel with the DMA interleaved between the taps (measured slower), 3 = wave-specialised 4 consumers (64 positions x 64 channels x 2 each) + 4 producers for the 9-tap layers
 extern "C" void ssie_debug_set_bf16_ws(int v) { ssie_bf16_ws = v; }
+int ssie_bf16_resw = 1;               // single-source 9-tap layers of <= 64 input channels: weights resident in LDS (1 = 8 consumer waves, 2 = 4; 0 = off)
+extern "C" void ssie_debug_set_bf16_resw(int v) { ssie_bf16_resw = v; }
 int ssie_launch_fprop_bf16(const ConvParams& p_in, hipStream_t st)
 {
     // Static tile assignment (tile += gridDim.x).  The dynamic queue of the fp32 kernels draws every tile with a returning
@@ -1000,23 +1012,31 @@ int ssie_launch_fprop_bf16(const ConvParams& p_in, hipStream_t st)
         // layers that end in the lean epilogue (bf16 output, ReLU or none, no residual / second output, whole 32-channel groups)
         // with 9 taps or 1 run the wave-specialised kernel
         const bool lean = p.out_bf16 && !p.addsrc && !p.out2 && (p.Cout % 32) == 0 && p.act != ACT_SIGMOID;
-        if (ssie_bf16_ws == 3 && lean && p.ntaps == 9 && p.hp_h * p.hp_w * 4 <= 2560 && !p.tile_counter) {
+        if (ssie_bf16_ws >= 1 && ssie_bf16_resw && lean && p.ntaps == 9 && p.nsrc == 1 && p.nchunks <= 2 && p.co_blocks == 1 &&
+            p.hp_h * p.hp_w * 4 <= 2560 && !p.tile_counter) {
+            static unsigned seen_rw[2] = {0, 0};
+            ssie_allow_full_lds((const void*)conv_fprop_bf16ws_kernel<9, true, 8, true>, seen_rw[0]);
+            ssie_allow_full_lds((const void*)conv_fprop_bf16ws_kernel<9, true, 4, true>, seen_rw[1]);
+            if (ssie_bf16_resw == 1) hipLaunchKernelGGL((conv_fprop_bf16ws_kernel<9, true, 8, true>), grid, dim3(768), lds, st, p);
+            else hipLaunchKernelGGL((conv_fprop_bf16ws_kernel<9, true, 4, true>), grid, dim3(512), lds, st, p);
+        }
+        else if (ssie_bf16_ws == 3 && lean && p.ntaps == 9 && p.hp_h * p.hp_w * 4 <= 2560 && !p.tile_counter) {
             static unsigned seen_w4[2] = {0, 0};
-            ssie_allow_full_lds((const void*)conv_fprop_bf16ws_kernel<9, false, 4>, seen_w4[0]);
-            ssie_allow_full_lds((const void*)conv_fprop_bf16ws_kernel<9, true, 4>, seen_w4[1]);
-            if (p.nsrc == 1) hipLaunchKernelGGL((conv_fprop_bf16ws_kernel<9, true, 4>), grid, dim3(512), lds, st, p);
-            else hipLaunchKernelGGL((conv_fprop_bf16ws_kernel<9, false, 4>), grid, dim3(512), lds, st, p);
+            ssie_allow_full_lds((const void*)conv_fprop_bf16ws_kernel<9, false, 4, false>, seen_w4[0]);
+            ssie_allow_full_lds((const void*)conv_fprop_bf16ws_kernel<9, true, 4, false>, seen_w4[1]);
+            if (p.nsrc == 1) hipLaunchKernelGGL((conv_fprop_bf16ws_kernel<9, true, 4, false>), grid, dim3(512), lds, st, p);
+            else hipLaunchKernelGGL((conv_fprop_bf16ws_kernel<9, false, 4, false>), grid, dim3(512), lds, st, p);
         }
         else if ((ssie_bf16_ws == 1 || ssie_bf16_ws == 3) && lean && (p.ntaps == 9 || p.ntaps == 1) && p.hp_h * p.hp_w * 4 <= 2560 && !p.tile_counter) {
             static unsigned seen_ws[4] = {0, 0, 0, 0};
-            ssie_allow_full_lds((const void*)conv_fprop_bf16ws_kernel<9, false, 8>, seen_ws[0]);
-            ssie_allow_full_lds((const void*)conv_fprop_bf16ws_kernel<9, true, 8>, seen_ws[1]);
-            ssie_allow_full_lds((const void*)conv_fprop_bf16ws_kernel<1, false, 8>, seen_ws[2]);
-            ssie_allow_full_lds((const void*)conv_fprop_bf16ws_kernel<1, true, 8>, seen_ws[3]);
-            if (p.ntaps == 9 && p.nsrc == 1) hipLaunchKernelGGL((conv_fprop_bf16ws_kernel<9, true, 8>), grid, dim3(768), lds, st, p);
-            else if (p.ntaps == 9) hipLaunchKernelGGL((conv_fprop_bf16ws_kernel<9, false, 8>), grid, dim3(768), lds, st, p);
-            else if (p.nsrc == 1) hipLaunchKernelGGL((conv_fprop_bf16ws_kernel<1, true, 8>), grid, dim3(768), lds, st, p);
-            else hipLaunchKernelGGL((conv_fprop_bf16ws_kernel<1, false, 8>), grid, dim3(768), lds, st, p);
+            ssie_allow_full_lds((const void*)conv_fprop_bf16ws_kernel<9, false, 8, false>, seen_ws[0]);
+            ssie_allow_full_lds((const void*)conv_fprop_bf16ws_kernel<9, true, 8, false>, seen_ws[1]);
+            ssie_allow_full_lds((const void*)conv_fprop_bf16ws_kernel<1, false, 8, false>, seen_ws[2]);
+            ssie_allow_full_lds((const void*)conv_fprop_bf16ws_kernel<1, true, 8, false>, seen_ws[3]);
+            if (p.ntaps == 9 && p.nsrc == 1) hipLaunchKernelGGL((conv_fprop_bf16ws_kernel<9, true, 8, false>), grid, dim3(768), lds, st, p);
+            else if (p.ntaps == 9) hipLaunchKernelGGL((conv_fprop_bf16ws_kernel<9, false, 8, false>), grid, dim3(768), lds, st, p);
+            else if (p.nsrc == 1) hipLaunchKernelGGL((conv_fprop_bf16ws_kernel<1, true, 8, false>), grid, dim3(768), lds, st, p);
+            else hipLaunchKernelGGL((conv_fprop_bf16ws_kernel<1, false, 8, false>), grid, dim3(768), lds, st, p);
         }
         else if (ssie_bf16_ws == 2 && p.ntaps == 9 && p.nsrc == 1) hipLaunchKernelGGL((conv_fprop_bf16w_kernel<5, true, true>), grid, dim3(512), lds, st, p);
         else if (ssie_bf16_ws == 2 && p.ntaps == 9) hipLaunchKernelGGL((conv_fprop_bf16w_kernel<5, false, true>), grid, dim3(512), lds, st, p);
