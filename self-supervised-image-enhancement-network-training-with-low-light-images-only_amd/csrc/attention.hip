@@ -4,8 +4,8 @@
 // layers (:104-106, :115-117) run on the MFMA 1x1-conv path.
 //
 // Tokens are the NHWC pixels of the bottleneck feature map, so the (N*T, 192) qkv buffer is read
-// directly; the forward is an fp32-MFMA flash attention (below); in the backward one thread owns one query row (dQ) or
-// one key row (dK, dV) and streams the other side through LDS in tiles of 256 rows, so any token count works (256 tokens
+// directly; the forward is an fp32-MFMA flash attention (below); in the backward eight threads share one query row (dQ) or
+// one key row (dK, dV) and stream the other side through LDS in tiles of 256 rows, so any token count works (256 tokens
 // for a 128x128 patch, 16 384 for a 1024x1024 image) without materialising the T x T logits.
 #include "attention.h"
 
@@ -258,26 +258,41 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const float* __restr
     }
 }
 
-// dQ: one thread per query row.  p_ij = exp(s_ij - lse_i), dS = p (dP - delta), dQ_i = scale * sum_j dS_ij K_j.
+// Backward.  A workgroup = 32 rows x 8 PARTS: thread (part, row) owns its row's share of every staged 256-row tile of the other
+// side (rows 32 part .. 32 part + 31 of the tile), and the eight partial results of a row are added through LDS in part order
+// (fixed order: bit-reproducible).  With one thread per row and 256 rows per workgroup a 128 x 128 patch batch (256 tokens x 4
+// heads x 32 images) was 128 workgroups of 256-iteration scalar loops: half the chip idle, 112 + 146 us; the split gives 1 024
+// workgroups of 32-iteration loops.  The two lane halves of a wave hold two parts, so a tile row read is an LDS broadcast.
+//
+// dQ: p_ij = exp(s_ij - lse_i), dS = p (dP - delta), dQ_i = scale * sum_j dS_ij K_j.
 // delta_i = sum_j p_ij dP_ij / sum_j p_ij is accumulated from the SAME p and dP that form dS (first sweep), so
 // sum_j dS_ij cancels to rounding like torch's softmax backward does; the cheaper dO.O form leaves an error
 // proportional to mean(K) that swamps the (often tiny) query/key gradients of this block.
+#define AB_ROWS 32
+#define AB_PARTS 8
+#define AB_SPAN (AT_TILE / AB_PARTS)
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ qkv, int qs,
                                                           const float* __restrict__ go, int os, const float* __restrict__ lse,
                                                           float* __restrict__ gqkv, float* __restrict__ delta, int T, float scale)
 {
-    __shared__ float Ks[AT_TILE][AT_D];
-    __shared__ float Vs[AT_TILE][AT_D];
+    __shared__ __attribute__((aligned(16))) float Ks[AT_TILE][AT_D];
+    __shared__ __attribute__((aligned(16))) float Vs[AT_TILE][AT_D];
+    __shared__ float red[AB_PARTS][AT_D + 1][AB_ROWS];
     const int tid = threadIdx.x, head = blockIdx.y, n = blockIdx.z;
-    const int qi = blockIdx.x * 256 + tid;
+    const int rl = tid & (AB_ROWS - 1), part = tid >> 5;
+    const int qi = blockIdx.x * AB_ROWS + rl;
     const float* base = qkv + (size_t)n * T * qs;
     float q[AT_D], dO[AT_D], dq[AT_D];
     float ls = 0.f;
 #pragma unroll
-    for (int d = 0; d < AT_D; ++d) {
-        q[d] = qi < T ? base[(size_t)qi * qs + head * AT_D + d] * scale : 0.f;
-        dO[d] = qi < T ? go[((size_t)n * T + qi) * os + head * AT_D + d] : 0.f;
-        dq[d] = 0.f;
+    for (int d4 = 0; d4 < AT_D; d4 += 4) {
+        f32x4 qv = {0.f, 0.f, 0.f, 0.f}, gv = qv;
+        if (qi < T) {
+            qv = *(const f32x4*)(base + (size_t)qi * qs + head * AT_D + d4);
+            gv = *(const f32x4*)(go + ((size_t)n * T + qi) * os + head * AT_D + d4);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { q[d4 + e] = qv[e] * scale; dO[d4 + e] = gv[e]; dq[d4 + e] = 0.f; }
     }
     if (qi < T) ls = lse[((size_t)n * 4 + head) * T + qi];
     float sp = 0.f, spd = 0.f, dl = 0.f;
@@ -294,8 +309,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
                 *(f32x4*)&Ks[r][c4] = kv; *(f32x4*)&Vs[r][c4] = vv;
             }
             __syncthreads();
-            const int kn = min(AT_TILE, T - k0);
-            for (int j = 0; j < kn; ++j) {
+            const int j0 = part * AB_SPAN, j1 = min(j0 + AB_SPAN, T - k0);
+            for (int j = j0; j < j1; ++j) {
                 float s = 0.f, dp = 0.f;
 #pragma unroll
                 for (int d = 0; d < AT_D; ++d) { s += q[d] * Ks[j][d]; dp += dO[d] * Vs[j][d]; }
@@ -309,33 +324,57 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
             }
         }
         if (sweep == 0) {
-            dl = spd / sp;
-            if (qi < T) delta[((size_t)n * 4 + head) * T + qi] = dl;
+            red[part][0][rl] = sp; red[part][1][rl] = spd;
+            __syncthreads();
+            float a = 0.f, c = 0.f;
+#pragma unroll
+            for (int p = 0; p < AB_PARTS; ++p) { a += red[p][0][rl]; c += red[p][1][rl]; }
+            dl = c / a;
+            if (part == 0 && qi < T) delta[((size_t)n * 4 + head) * T + qi] = dl;
         }
     }
-    if (qi < T)
+    __syncthreads();
 #pragma unroll
-        for (int d = 0; d < AT_D; ++d) gqkv[((size_t)n * T + qi) * qs + head * AT_D + d] = dq[d] * scale;
+    for (int d = 0; d < AT_D; ++d) red[part][d][rl] = dq[d];
+    __syncthreads();
+    // thread (part, row) adds dims 2 part, 2 part + 1 of its row over the eight parts
+    if (qi < T) {
+        float o2[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float a = 0.f;
+#pragma unroll
+            for (int p = 0; p < AB_PARTS; ++p) a += red[p][2 * part + e][rl];
+            o2[e] = a * scale;
+        }
+        *(float2*)(gqkv + ((size_t)n * T + qi) * qs + head * AT_D + 2 * part) = make_float2(o2[0], o2[1]);
+    }
 }
 
-// dK, dV: one thread per key row, queries streamed through LDS
+// dK, dV: 32 key rows x 8 parts per workgroup, queries (with their dO, lse, delta) streamed through LDS
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, int qs, const float* __restrict__ go, int os,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            float* __restrict__ gqkv, int T, float scale)
 {
-    __shared__ float Qs[AT_TILE][AT_D];
-    __shared__ float Gs[AT_TILE][AT_D];
+    __shared__ __attribute__((aligned(16))) float QG[2][AT_TILE][AT_D];          // one array: the reduction below reuses both halves
+    float (*Qs)[AT_D] = QG[0];
+    float (*Gs)[AT_D] = QG[1];
     __shared__ float Ls[AT_TILE];
     __shared__ float Ds[AT_TILE];
     const int tid = threadIdx.x, head = blockIdx.y, n = blockIdx.z;
-    const int kj = blockIdx.x * 256 + tid;
+    const int rl = tid & (AB_ROWS - 1), part = tid >> 5;
+    const int kj = blockIdx.x * AB_ROWS + rl;
     const float* base = qkv + (size_t)n * T * qs;
     float k[AT_D], v[AT_D], dk[AT_D], dv[AT_D];
 #pragma unroll
-    for (int d = 0; d < AT_D; ++d) {
-        k[d] = kj < T ? base[(size_t)kj * qs + 64 + head * AT_D + d] : 0.f;
-        v[d] = kj < T ? base[(size_t)kj * qs + 128 + head * AT_D + d] : 0.f;
-        dk[d] = 0.f; dv[d] = 0.f;
+    for (int d4 = 0; d4 < AT_D; d4 += 4) {
+        f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
+        if (kj < T) {
+            kv = *(const f32x4*)(base + (size_t)kj * qs + 64 + head * AT_D + d4);
+            vv = *(const f32x4*)(base + (size_t)kj * qs + 128 + head * AT_D + d4);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { k[d4 + e] = kv[e]; v[d4 + e] = vv[e]; dk[d4 + e] = 0.f; dv[d4 + e] = 0.f; }
     }
     for (int q0 = 0; q0 < T; q0 += AT_TILE) {
         __syncthreads();
@@ -350,8 +389,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
         }
         if (q0 + tid < T) { Ls[tid] = lse[((size_t)n * 4 + head) * T + q0 + tid]; Ds[tid] = delta[((size_t)n * 4 + head) * T + q0 + tid]; }
         __syncthreads();
-        const int qn = min(AT_TILE, T - q0);
-        for (int i = 0; i < qn; ++i) {
+        const int i0 = part * AB_SPAN, i1 = min(i0 + AB_SPAN, T - q0);
+        for (int i = i0; i < i1; ++i) {
             float s = 0.f, dp = 0.f;
 #pragma unroll
             for (int d = 0; d < AT_D; ++d) { s += Qs[i][d] * k[d]; dp += Gs[i][d] * v[d]; }
@@ -361,12 +400,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
             for (int d = 0; d < AT_D; ++d) { dv[d] += pij * Gs[i][d]; dk[d] += ds * Qs[i][d]; }
         }
     }
-    if (kj < T)
+    // partial sums of the eight parts, added in part order; the tile buffers are free now: red[part][0..31][row]
+    __syncthreads();
+    float (*red)[2 * AT_D][AB_ROWS] = (float (*)[2 * AT_D][AB_ROWS])&QG[0][0][0];      // 8 x 32 x 32 floats = Qs + Gs
+    static_assert(sizeof(float) * AB_PARTS * 2 * AT_D * AB_ROWS <= 2 * sizeof(float) * AT_TILE * AT_D, "reduction scratch does not fit the tile buffers");
 #pragma unroll
-        for (int d = 0; d < AT_D; ++d) {
-            gqkv[((size_t)n * T + kj) * qs + 64 + head * AT_D + d] = dk[d] * scale;
-            gqkv[((size_t)n * T + kj) * qs + 128 + head * AT_D + d] = dv[d];
+    for (int d = 0; d < AT_D; ++d) { red[part][d][rl] = dk[d]; red[part][AT_D + d][rl] = dv[d]; }
+    __syncthreads();
+    if (kj < T) {
+        // thread (part, row): values 4 part .. 4 part + 3 of the row's 32 (dK | dV)
+        float o4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = 0.f;
+#pragma unroll
+            for (int p = 0; p < AB_PARTS; ++p) a += red[p][4 * part + e][rl];
+            o4[e] = part < 4 ? a * scale : a;
         }
+        float* dst = gqkv + ((size_t)n * T + kj) * qs + head * AT_D + (part < 4 ? 64 + 4 * part : 128 + 4 * (part - 4));
+        *(f32x4*)dst = f32x4{o4[0], o4[1], o4[2], o4[3]};
+    }
 }
 
 int ssie_launch_attn_fwd(const float* qkv, int qs, float* o, int os, float* lse, int N, int T, hipStream_t st)
@@ -387,7 +440,7 @@ int ssie_launch_attn_fwd_bf16(const float* qkv, int qs, void* o, int os, int N, 
 int ssie_launch_attn_bwd(const float* qkv, int qs, const float* o, const float* go, int os, const float* lse,
                          float* delta, float* gqkv, int N, int T, hipStream_t st)
 {
-    dim3 grid((T + 255) / 256, 4, N);
+    dim3 grid((T + AB_ROWS - 1) / AB_ROWS, 4, N);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, qkv, qs, go, os, lse, gqkv, delta, T, 0.25f);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, qkv, qs, go, os, lse, delta, gqkv, T, 0.25f);
     return hipGetLastError() == hipSuccess ? 0 : 62;
