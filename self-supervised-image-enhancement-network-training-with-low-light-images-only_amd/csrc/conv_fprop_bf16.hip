@@ -955,6 +955,196 @@ template __global__ void conv_fprop_bf16ws_kernel<9, true, 8, true>(const ConvPa
 template __global__ void conv_fprop_bf16ws_kernel<9, true, 4, true>(const ConvParams);
 
 
+// The 9 x 9 layer (shallow_conv, <= 32 input channels -> 64) on the wave-specialised structure: tile = 16 x 32 positions x 64
+// channels, 8 consumer waves (64 positions x 64 channels each) + 4 producer waves.  The layer's packed weights are 332 KB, so
+// they stream through LDS once per TILE, one kernel row (9 taps, 36.9 KB) per step, double-buffered; the generic kernel's
+// 16 x 16 tile made that 369 KB of LDS-DMA per 20 k cycles of MFMA work - DMA-bound (0.43 ms for a 0.14 ms MFMA floor) - and its
+// 64 x 32 wave tile read 1.5 fragments per MFMA.  Here a tile moves 393 KB for 41 k MFMA cycles and a wave reads one per MFMA.
+//   * halo tile 24 x 40 pixels x 32 channels (61 KB), ONE buffer: all nine steps of a tile read it.  Row pitch 40 is not a
+//     multiple of 16 pixels, so the slot swizzle of kernel row g differs from row 0's by (10 g) & 3 = 2 (g & 1): odd rows swap
+//     the two k-halves (address ^ 32) - the per-tap addresses are computed once per kernel, a step adds g * 2560 bytes
+//   * barriers: one per step (weights of the step landed / the other weight buffer free) and one at the end of a tile, after
+//     which the producers overwrite the halo with the next tile's while the consumers run their epilogue
+// Static tile assignment; lean epilogue (bf16 output, ReLU or none) with 16-byte stores.
+__global__ __launch_bounds__(768) void conv9x9_bf16ws_kernel(const ConvParams p, int tiles_x, int tiles_y)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    constexpr int NT = 2, NWC = 8, NWP = 4, BN = 64, TH = 16, TWW = 32, MT = 2;
+    constexpr int HPH = 24, HPW = 40, HP4 = HPH * HPW * 4;          // 3 840 16-byte slots = 15 DMA rounds of the 256 producer lanes
+    constexpr int PTHR = 64 * NWP, NTHR = 64 * (NWC + NWP), NAP = HP4 / PTHR;
+    static_assert(HP4 % PTHR == 0, "halo slots must fill whole DMA rounds");
+    constexpr int BSZ = SSIE_TG * 4 * BN;
+    constexpr int ROWB = HPW * 64;                                   // bytes per halo row
+    f32x4* As0 = (f32x4*)smem_f;                    // [HP4]
+    f32x4* Bs0 = As0 + HP4;                         // [2][BSZ]
+    float* bias_s = (float*)(Bs0 + 2 * BSZ);        // [64]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, li = lane & 31;
+    for (int t = tid; t < 64; t += NTHR) bias_s[t] = (p.bias && t < p.Cout) ? p.bias[t] : 0.f;
+    __syncthreads();
+
+    const int total_tiles = p.N * tiles_y * tiles_x;
+    int tile = blockIdx.x;
+    if (tile >= total_tiles) return;
+#define N9_DECODE(T, N_, A0_, B0_) { int q_ = (T); B0_ = (q_ % tiles_x) * TWW; q_ /= tiles_x; A0_ = (q_ % tiles_y) * TH; N_ = q_ / tiles_y; }
+    int n, a0, b0;
+    N9_DECODE(tile, n, a0, b0)
+
+    if (wave >= NWC) {
+        // ------------------------------------------------ producers ------------------------------------------------
+        const int ptid = tid - 64 * NWC, pwave = wave - NWC;
+        int ahy[NAP], ahx[NAP], aj[NAP];
+#pragma unroll
+        for (int i = 0; i < NAP; ++i) {
+            const int id = ptid + i * PTHR, pix = id >> 2;
+            ahy[i] = pix / HPW; ahx[i] = pix - ahy[i] * HPW; aj[i] = (id & 3) ^ ssie_swz(pix);
+        }
+        const SrcSel s = ssie_only_src(p);
+#define N9_HALO(N_, A0_, B0_)                                                                                 \
+        {                                                                                                     \
+            const int vy0_ = (A0_) - 4, vx0_ = (B0_) - 4;                                                     \
+            if ((s.C & 31) == 0 && vy0_ >= 0 && vx0_ >= 0 && vy0_ + HPH <= p.Hv && vx0_ + HPW <= p.Wv) {     \
+                const unsigned short* sb_ = (const unsigned short*)s.ptr + ((size_t)((N_) * s.Hs + vy0_) * s.Ws + vx0_) * s.cstride + s.coff; \
+                _Pragma("unroll") for (int i_ = 0; i_ < NAP; ++i_)                                            \
+                    GLDS16(sb_ + (ahy[i_] * s.Ws + ahx[i_]) * s.cstride + 8 * aj[i_], As0 + i_ * PTHR + pwave * 64); \
+            } else {                                                                                          \
+                _Pragma("unroll") for (int i_ = 0; i_ < NAP; ++i_)                                            \
+                    GLDS16(ssie_virtual_addr_h(s, false, (N_), vy0_ + ahy[i_], vx0_ + ahx[i_], p.Hv, p.Wv, 8 * aj[i_]), As0 + i_ * PTHR + pwave * 64); \
+            }                                                                                                 \
+        }
+#define N9_WEIGHTS(G, BUF)                                                                                    \
+        {                                                                                                     \
+            const f32x4* wsrc_ = (const f32x4*)p.wpacked + ((size_t)((G) * SSIE_TG) * 4) * 64;                \
+            f32x4* bbuf_ = Bs0 + (BUF) * BSZ;                                                                 \
+            for (int q_ = pwave; q_ < SSIE_TG * 4; q_ += NWP) GLDS16(wsrc_ + (size_t)q_ * 64 + lane, bbuf_ + q_ * 64); \
+        }
+        N9_HALO(n, a0, b0)
+        N9_WEIGHTS(0, 0)
+        int gstep = 0;
+        while (tile < total_tiles) {
+            const int ntile = tile + (int)gridDim.x;
+            for (int g = 0; g < 9; ++g, ++gstep) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (g < 8) N9_WEIGHTS(g + 1, (gstep + 1) & 1)
+                else if (ntile < total_tiles) N9_WEIGHTS(0, (gstep + 1) & 1)
+            }
+            asm volatile("s_barrier" ::: "memory");             // the consumers have read the halo tile for the last time
+            tile = ntile;
+            if (tile < total_tiles) { N9_DECODE(tile, n, a0, b0) N9_HALO(n, a0, b0) }
+        }
+#undef N9_WEIGHTS
+#undef N9_HALO
+        return;
+    }
+
+    // ---------------------------------------------------- consumers ----------------------------------------------------
+    // byte offset inside the halo tile of (M-tile m, tap column dx, kernel row 0, k-quad 0)
+    int aaddr[SSIE_TG][MT];
+#pragma unroll
+    for (int t = 0; t < SSIE_TG; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int hp = (2 * wave + (li >> 4)) * HPW + 16 * m + (li & 15) + t;
+            aaddr[t][m] = (hp * 4 + (h ^ ssie_swz(hp))) * 16;
+        }
+    const float relu_lo = p.act == ACT_RELU ? 0.f : -3.0e38f;
+    int lane_off[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) lane_off[m] = ((2 * wave + (li >> 4)) * p.Wout + 16 * m + (li & 15)) * p.out_cstride + 8 * h;
+
+    int gstep = 0;
+    while (tile < total_tiles) {
+        f32x16 acc[MT][NT];
+        {
+            const float* bsrc = bias_s + 4 * h;
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 b = *(const f32x4*)(bsrc + 32 * c + 8 * g4);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[m][c][4 * g4 + j] = b[j];
+                }
+        }
+        for (int g = 0; g < 9; ++g, ++gstep) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const char* Ab = (const char*)As0 + g * ROWB;
+            const int xg = (g & 1) * 32;                        // odd kernel rows: the k-halves trade places (header)
+            const f32x4* Bl = Bs0 + (gstep & 1) * BSZ + h * BN + li;
+#define N9_LD(BF, AF, TL, SC)                                                                             \
+            {                                                                                             \
+                _Pragma("unroll") for (int c_ = 0; c_ < NT; ++c_) BF[c_] = Bl[((TL) * 4 + (SC) * 2) * BN + c_ * 32]; \
+                _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_)                                         \
+                    AF[m_] = *(const f32x4*)(Ab + (aaddr[TL][m_] ^ ((SC) ? (xg ^ 32) : xg)));             \
+            }
+#define N9_MFMA(BF, AF)                                                                                   \
+            _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_)                                             \
+            _Pragma("unroll") for (int c_ = 0; c_ < NT; ++c_) acc[m_][c_] = MFMA_BF16(BF[c_], AF[m_], acc[m_][c_]);
+            {
+                f32x4 bX[NT], bY[NT], aX[MT], aY[MT];
+                N9_LD(bX, aX, 0, 0)
+#pragma unroll
+                for (int tl = 0; tl < SSIE_TG; ++tl) {
+                    N9_LD(bY, aY, tl, 1)
+                    N9_MFMA(bX, aX)
+                    if (tl + 1 < SSIE_TG) N9_LD(bX, aX, (tl + 1 < SSIE_TG ? tl + 1 : 0), 0)
+                    N9_MFMA(bY, aY)
+                }
+            }
+#undef N9_LD
+#undef N9_MFMA
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // end of tile: the halo buffer may be overwritten
+
+        const bool inside = a0 + TH <= p.Hout && b0 + TWW <= p.Wout;
+        if (inside) {
+            unsigned short* tbase = (unsigned short*)p.out + ((size_t)(n * p.Hout + a0) * p.Wout + b0) * p.out_cstride + p.out_coff;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int c = 0; c < NT; ++c)
+#pragma unroll
+                    for (int g2 = 0; g2 < 4; g2 += 2) {
+                        const f32x16& a = acc[m][c];
+                        uint2 u[2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e)
+                            u[e] = make_uint2(ssie_pack2bf(fmaxf(a[4 * (g2 + e)], relu_lo), fmaxf(a[4 * (g2 + e) + 1], relu_lo)),
+                                              ssie_pack2bf(fmaxf(a[4 * (g2 + e) + 2], relu_lo), fmaxf(a[4 * (g2 + e) + 3], relu_lo)));
+                        *(uint4*)(tbase + lane_off[m] + 32 * c + 8 * g2) = ssie_pair_swap(u[0], u[1]);
+                    }
+        } else {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int oy = a0 + 2 * wave + (li >> 4), ox = b0 + 16 * m + (li & 15);
+                const bool ok = oy < p.Hout && ox < p.Wout;
+                unsigned short* ob = (unsigned short*)p.out + ((size_t)(n * p.Hout + oy) * p.Wout + ox) * p.out_cstride + p.out_coff + 8 * h;
+#pragma unroll
+                for (int c = 0; c < NT; ++c)
+#pragma unroll
+                    for (int g2 = 0; g2 < 4; g2 += 2) {
+                        const f32x16& a = acc[m][c];
+                        uint2 u[2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e)
+                            u[e] = make_uint2(ssie_pack2bf(fmaxf(a[4 * (g2 + e)], relu_lo), fmaxf(a[4 * (g2 + e) + 1], relu_lo)),
+                                              ssie_pack2bf(fmaxf(a[4 * (g2 + e) + 2], relu_lo), fmaxf(a[4 * (g2 + e) + 3], relu_lo)));
+                        const uint4 v = ssie_pair_swap(u[0], u[1]);
+                        if (ok) *(uint4*)(ob + 32 * c + 8 * g2) = v;
+                    }
+            }
+        }
+        tile += (int)gridDim.x;
+        if (tile < total_tiles) N9_DECODE(tile, n, a0, b0)
+    }
+#undef N9_DECODE
+}
+
+
 
 template __global__ void conv_fprop_bf16w_kernel<5, false, false>(const ConvParams);
 template __global__ void conv_fprop_bf16w_kernel<5, true, false>(const ConvParams);
@@ -984,6 +1174,9 @@ static int launch_h_t(const ConvParams& p, size_t lds, hipStream_t st)
 int ssie_bf16_dynamic_queue = 0;      // see below
 int ssie_bf16_ws = 3;                 // 16 x 32 geometry: 0 = eight-wave kernel, 1 = wave-specialised 8 consumers + 4 producers, 2 = eight-wave kernel with the DMA interleaved between the taps (measured slower), 3 = wave-specialised 4 consumers (64 positions x 64 channels x 2 each) + 4 producers for the 9-tap layers
 extern "C" void ssie_debug_set_bf16_ws(int v) { ssie_bf16_ws = v; }
+int ssie_bf16_conv9 = 1, ssie_bf16_conv9_min_tiles = 256;   // the 9 x 9 layer on conv9x9_bf16ws_kernel (16 x 32 tiles) from this many tiles on
+extern "C" void ssie_debug_set_bf16_conv9(int v) { ssie_bf16_conv9 = v; }
+extern "C" void ssie_debug_set_bf16_conv9_min_tiles(int v) { ssie_bf16_conv9_min_tiles = v; }
 int ssie_bf16_resw = 1;               // single-source 9-tap layers of <= 64 input channels: weights resident in LDS (1 = 8 consumer waves, 2 = 4; 0 = off)
 extern "C" void ssie_debug_set_bf16_resw(int v) { ssie_bf16_resw = v; }
 int ssie_launch_fprop_bf16(const ConvParams& p_in, hipStream_t st)
@@ -993,6 +1186,21 @@ int ssie_launch_fprop_bf16(const ConvParams& p_in, hipStream_t st)
     // atomics (serialised at the memory side) and their in-order return behind the prefetch DMA set the pace.
     ConvParams p = p_in;
     if (!ssie_bf16_dynamic_queue) p.tile_counter = nullptr;
+    if (ssie_bf16_conv9 && p.ntaps == 81 && p.si == 1 && p.so == 1 && p.py == 0 && p.px == 0 && p.nchunks == 1 && p.Cout_pad == 64 &&
+        p.nsrc == 1 && p.src[0].sy == 1.f && p.src[0].sx == 1.f && p.min_dy == -4 && p.min_dx == -4 && p.Ho == p.Hout && p.Wo == p.Wout &&
+        p.out_bf16 && !p.addsrc && !p.out2 && (p.Cout % 32) == 0 && p.act != ACT_SIGMOID) {
+        bool rowmajor = true;
+        for (int t = 0; t < 81; ++t) rowmajor = rowmajor && p.tap_dy[t] == t / 9 - 4 && p.tap_dx[t] == t % 9 - 4;
+        const int tx = ssie_ceil_div(p.Wo, 32), ty = ssie_ceil_div(p.Ho, 16);
+        const size_t tiles = (size_t)p.N * tx * ty;
+        if (rowmajor && tiles >= (size_t)ssie_bf16_conv9_min_tiles) {
+            static unsigned seen9 = 0;
+            ssie_allow_full_lds((const void*)conv9x9_bf16ws_kernel, seen9);
+            const size_t lds9 = (size_t)(24 * 40 * 4 + 2 * SSIE_TG * 4 * 64) * 16 + 64 * 4;
+            hipLaunchKernelGGL(conv9x9_bf16ws_kernel, dim3((unsigned)(tiles < 256 ? tiles : 256)), dim3(768), lds9, st, p, tx, ty);
+            return hipGetLastError() == hipSuccess ? 0 : 66;
+        }
+    }
     const int nt = (p.Cout_pad % 64 == 0) ? 2 : 1;
     const int na2 = (p.hp_h * p.hp_w * 4 + 511) / 512;
     const size_t lds = lds_bytes_h(p, nt);

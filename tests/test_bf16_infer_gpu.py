@@ -33,12 +33,15 @@ def _plan(H, n, bands, h, w):
 
 @pytest.fixture(params=["heuristic", "tile16x32"])
 def wide_tiles(H, request):
-    """"tile16x32" forces conv_fprop_bf16w_kernel (the 16 x 32-tile kernel of the 1024 x 1024 layers) onto these small cubes"""
+    """"tile16x32" forces the 16 x 32-tile kernels of the 1024 x 1024 layers (the wave-specialised 3 x 3 / 1 x 1 kernels and the
+    9 x 9 kernel) onto these small cubes, ragged edge tiles included"""
     L = H.lib()
     if request.param == "tile16x32":
         L.ssie_debug_set_fprop_wide_min_tiles(1)
+        L.ssie_debug_set_bf16_conv9_min_tiles(1)
     yield request.param
     L.ssie_debug_set_fprop_wide_min_tiles(512)
+    L.ssie_debug_set_bf16_conv9_min_tiles(256)
 
 
 @pytest.mark.parametrize("n,bands,h,w", [(2, 31, 64, 64), (1, 31, 50, 38), (1, 31, 136, 200), (1, 7, 32, 32)])
