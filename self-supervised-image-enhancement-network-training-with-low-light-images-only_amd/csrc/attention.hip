@@ -258,6 +258,157 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const float* __restr
     }
 }
 
+// ---- bf16 forward with PRE-CONVERTED keys / values (the 16 384-token enhance-only image) ----
+// attn_fwd_bf16_kernel converts and permutes the K / V slab it stages for every 128 queries: at 16 384 tokens that is 512
+// workgroups x 2 MB of fp32 reads, 16-byte loads at a 768-byte stride, 2-byte LDS scatter writes and no prefetch - the staging,
+// not the softmax, was half the kernel.  attn_kv_bf16_kernel does the conversion ONCE into a scratch buffer in exactly the LDS
+// image of a slab (Kh[key][16] and the permuted, row-padded Vt[block][dim][40]), and attn_fwd_bf16p_kernel stages slab s + 1 by
+// LDS-DMA (18 pieces of 1 KB) under the MFMAs and softmax of slab s.
+__global__ __launch_bounds__(256) void attn_kv_bf16_kernel(const float* __restrict__ qkv, int qs, unsigned short* __restrict__ kg,
+                                                           unsigned short* __restrict__ vg, int T, int Tpad)
+{
+    const int key = blockIdx.x * 64 + (threadIdx.x >> 2), head = threadIdx.x & 3, n = blockIdx.y;
+    if (key >= Tpad) return;
+    f32x4 kv[4], vv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        kv[c] = f32x4{0.f, 0.f, 0.f, 0.f}; vv[c] = kv[c];
+        if (key < T) {
+            kv[c] = *(const f32x4*)(qkv + ((size_t)n * T + key) * qs + 64 + head * AT_D + 4 * c);
+            vv[c] = *(const f32x4*)(qkv + ((size_t)n * T + key) * qs + 128 + head * AT_D + 4 * c);
+        }
+    }
+    unsigned short* kd = kg + (((size_t)n * 4 + head) * Tpad + key) * 16;
+    *(uint4*)kd = make_uint4(at_pack2(kv[0][0], kv[0][1]), at_pack2(kv[0][2], kv[0][3]), at_pack2(kv[1][0], kv[1][1]), at_pack2(kv[1][2], kv[1][3]));
+    *(uint4*)(kd + 8) = make_uint4(at_pack2(kv[2][0], kv[2][1]), at_pack2(kv[2][2], kv[2][3]), at_pack2(kv[3][0], kv[3][1]), at_pack2(kv[3][2], kv[3][3]));
+    const int k32 = key & 31, blk = key >> 5;
+    const int rr = (k32 & 3) + 4 * (k32 >> 3), hh = (k32 >> 2) & 1;
+    const int pos = (rr >> 3) * 16 + hh * 8 + (rr & 7);
+    unsigned short* vd = vg + ((((size_t)n * 4 + head) * (Tpad / 32) + blk) * 16) * AV_LD + pos;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) vd[d * AV_LD] = (unsigned short)at_f2bf(vv[d >> 2][d & 3]);
+}
+
+#define ATP_GLDS16(gptr, lptr)                                                                         \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),            \
+                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+__global__ __launch_bounds__(256) void attn_fwd_bf16p_kernel(const float* __restrict__ qkv, int qs, const unsigned short* __restrict__ kg,
+                                                             const unsigned short* __restrict__ vg, unsigned short* __restrict__ o, int os,
+                                                             int T, int Tpad, float scale)
+{
+    constexpr int KSL = AK_ST * 16, VSL = (AK_ST / 32) * 16 * AV_LD;         // ushorts per K / V slab: 8 KB and 10 KB
+    __shared__ __attribute__((aligned(16))) unsigned short Kh[2][KSL];
+    __shared__ __attribute__((aligned(16))) unsigned short Vt[2][VSL];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, li = lane & 31;
+    const int head = blockIdx.y, n = blockIdx.z;
+    const int qi = blockIdx.x * 128 + wave * 32 + li;
+    const float* base = qkv + (size_t)n * T * qs;
+    const float LOG2E = 1.4426950408889634f;
+    const unsigned short* kh_g = kg + ((size_t)n * 4 + head) * Tpad * 16;
+    const unsigned short* vt_g = vg + ((size_t)n * 4 + head) * (Tpad / 32) * 16 * AV_LD;
+
+    uint4 qb;
+    {
+        f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0;
+        if (qi < T) {
+            q0 = *(const f32x4*)(base + (size_t)qi * qs + head * AT_D + 8 * h);
+            q1 = *(const f32x4*)(base + (size_t)qi * qs + head * AT_D + 8 * h + 4);
+        }
+        const float c = scale * LOG2E;
+        qb = make_uint4(at_pack2(q0[0] * c, q0[1] * c), at_pack2(q0[2] * c, q0[3] * c), at_pack2(q1[0] * c, q1[1] * c), at_pack2(q1[2] * c, q1[3] * c));
+    }
+    f32x16 oacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+    // minus the reference of the logits (see the loop); the first block sets it
+    f32x16 negm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+    float lsum = 0.f;
+
+    // one slab = 8 K pieces + 10 V pieces of 1 KB (64 lanes x 16 B): wave w takes K pieces 2w, 2w + 1 and V pieces w, w + 4 (, w + 8)
+#define ATP_STAGE(SLAB, BUF)                                                                                          \
+    {                                                                                                                 \
+        const unsigned short* ks_ = kh_g + (size_t)(SLAB) * KSL;                                                      \
+        const unsigned short* vs_ = vt_g + (size_t)(SLAB) * VSL;                                                      \
+        _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_)                                                              \
+            ATP_GLDS16(ks_ + (2 * wave + q_) * 512 + lane * 8, &Kh[BUF][(2 * wave + q_) * 512]);                      \
+        _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_)                                                              \
+            if (wave + 4 * q_ < VSL / 512) ATP_GLDS16(vs_ + (wave + 4 * q_) * 512 + lane * 8, &Vt[BUF][(wave + 4 * q_) * 512]); \
+    }
+    const int nslab = Tpad / AK_ST;
+    ATP_STAGE(0, 0)
+    for (int s = 0; s < nslab; ++s) {
+        const int buf = s & 1, k0 = s * AK_ST;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (s + 1 < nslab) ATP_STAGE(s + 1, buf ^ 1)
+        const unsigned short* Kb = Kh[buf];
+        const unsigned short* Vb = Vt[buf];
+        // the logits of block sub + 1 are issued before the softmax of block sub: the MFMA -> max -> exp -> pack -> MFMA chain of
+        // one block is serial, and two waves per SIMD do not cover it
+        f32x16 stn = MFMA_BF16(*(const uint4*)(Kb + li * 16 + 8 * h), qb, negm);
+#pragma unroll
+        for (int sub = 0; sub < AK_ST / 32; ++sub) {
+            const int lr = sub * 32;
+            const int kb = k0 + lr;
+            if (kb >= T) break;
+            // LAZY running maximum: the accumulator starts at -m (negm: 16 registers that only change on the slow path), so the
+            // MFMA returns s - m directly, and the state is re-based only when a logit of this block exceeds the reference by
+            // more than 2^8 (softmax is invariant to the reference; 2^8 is far inside fp32 / bf16 range).  After the first
+            // blocks that is rare, and the common path per block is: one MFMA, a max tree + one wave vote, 16 v_exp_f32, the row
+            // sum, 8 packed converts, two MFMAs - about half the vector instructions of the eager form, which is what bounds this
+            // kernel (head dimension 16: 3 MFMAs per 1 024 logits).
+            f32x16 st = stn;
+            if (sub + 1 < AK_ST / 32) stn = MFMA_BF16(*(const uint4*)(Kb + (lr + 32 + li) * 16 + 8 * h), qb, negm);
+            if (kb + 32 > T) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kb + (r & 3) + 8 * (r >> 2) + 4 * h >= T) st[r] = -INFINITY;
+            }
+            float mb = fmaxf(fmaxf(st[0], st[1]), st[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) mb = fmaxf(fmaxf(mb, st[r]), st[r + 1]);
+            mb = fmaxf(mb, st[15]);
+            const bool first = s == 0 && sub == 0;                  // the very first block sets the reference to its own maximum
+            if (first || __builtin_amdgcn_ballot_w64(mb > 8.f)) {
+                // slow path (whole wave): both lane halves of a query share the reference
+                mb = fmaxf(mb, __shfl_xor(mb, 32));
+                const float d = first ? mb : fmaxf(mb, 0.f);        // afterwards the reference only ever rises
+                const float alpha = __builtin_amdgcn_exp2f(-d);
+                lsum *= alpha;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) oacc[r] *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { st[r] -= d; stn[r] -= d; negm[r] -= d; }          // (the prefetched block was formed against the old reference)
+            }
+            float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                st[r] = __builtin_amdgcn_exp2f(st[r]); st[r + 1] = __builtin_amdgcn_exp2f(st[r + 1]);
+                ps0 += st[r]; ps1 += st[r + 1];
+            }
+            lsum += ps0 + ps1;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint4 va = *(const uint4*)(Vb + (sub * 16 + (li & 15)) * AV_LD + j * 16 + h * 8);
+                const uint4 pb = make_uint4(at_pack2(st[8 * j + 0], st[8 * j + 1]), at_pack2(st[8 * j + 2], st[8 * j + 3]),
+                                            at_pack2(st[8 * j + 4], st[8 * j + 5]), at_pack2(st[8 * j + 6], st[8 * j + 7]));
+                oacc = MFMA_BF16(va, pb, oacc);
+            }
+        }
+    }
+#undef ATP_STAGE
+    lsum += __shfl_xor(lsum, 32);
+    if (qi < T) {
+        const float inv = 1.f / lsum;
+        unsigned short* op = o + ((size_t)n * T + qi) * os + head * AT_D + 4 * h;
+        *(uint2*)op = make_uint2(at_pack2(oacc[0] * inv, oacc[1] * inv), at_pack2(oacc[2] * inv, oacc[3] * inv));
+        *(uint2*)(op + 8) = make_uint2(at_pack2(oacc[4] * inv, oacc[5] * inv), at_pack2(oacc[6] * inv, oacc[7] * inv));
+    }
+}
+
 // Backward.  A workgroup = 32 rows x 8 PARTS: thread (part, row) owns its row's share of every staged 256-row tile of the other
 // side (rows 32 part .. 32 part + 31 of the tile), and the eight partial results of a row are added through LDS in part order
 // (fixed order: bit-reproducible).  With one thread per row and 256 rows per workgroup a 128 x 128 patch batch (256 tokens x 4
@@ -430,8 +581,25 @@ int ssie_launch_attn_fwd(const float* qkv, int qs, float* o, int os, float* lse,
 }
 
 // qkv fp32 (N*T, qs); o bf16 (N*T, os)
-int ssie_launch_attn_fwd_bf16(const float* qkv, int qs, void* o, int os, int N, int T, hipStream_t st)
+int ssie_attn_bf16_prepass = 1;       // ssie_debug_set_attn_bf16_prepass: 0 = every workgroup converts the K / V slabs it stages
+extern "C" void ssie_debug_set_attn_bf16_prepass(int v) { ssie_attn_bf16_prepass = v; }
+size_t ssie_attn_bf16_scratch_bytes(int N, int T)
 {
+    const size_t Tpad = (size_t)(T + AK_ST - 1) / AK_ST * AK_ST;
+    return (size_t)N * 4 * Tpad * 16 * 2 + (size_t)N * 4 * (Tpad / 32) * 16 * AV_LD * 2;
+}
+// scratch (optional): ssie_attn_bf16_scratch_bytes(N, T) bytes for the pre-converted keys / values
+int ssie_launch_attn_fwd_bf16(const float* qkv, int qs, void* o, int os, int N, int T, hipStream_t st, void* scratch, size_t scratch_bytes)
+{
+    if (ssie_attn_bf16_prepass && scratch && T >= AK_ST && scratch_bytes >= ssie_attn_bf16_scratch_bytes(N, T)) {
+        const int Tpad = (T + AK_ST - 1) / AK_ST * AK_ST;
+        unsigned short* kg = (unsigned short*)scratch;
+        unsigned short* vg = kg + (size_t)N * 4 * Tpad * 16;
+        hipLaunchKernelGGL(attn_kv_bf16_kernel, dim3(Tpad / 64, N), dim3(256), 0, st, qkv, qs, kg, vg, T, Tpad);
+        hipLaunchKernelGGL(attn_fwd_bf16p_kernel, dim3((T + 127) / 128, 4, N), dim3(256), 0, st, qkv, qs, (const unsigned short*)kg,
+                           (const unsigned short*)vg, (unsigned short*)o, os, T, Tpad, 0.25f);
+        return hipGetLastError() == hipSuccess ? 0 : 64;
+    }
     dim3 grid((T + 127) / 128, 4, N);
     hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid, dim3(256), 0, st, qkv, qs, (unsigned short*)o, os, T, 0.25f);
     return hipGetLastError() == hipSuccess ? 0 : 63;

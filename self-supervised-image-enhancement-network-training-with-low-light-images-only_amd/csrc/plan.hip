@@ -540,7 +540,9 @@ int build_illum_fwd(Builder& b, std::vector<Fn>& ops, bool fused_tail = false)
         const int N = pl.N, T = H8 * W8;
         if (b.h16) {
             float* aoh = pl.buf("aoh");
-            ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_attn_fwd_bf16(qkv, 192, aoh, 64, N, T, st); }, K_ATTN, 4.0 * N * 4 * (double)T * T * 16));
+            // pre-converted bf16 keys / values go into "gqkv" (a backward-pass tensor: idle during the enhance-only forward)
+            float* kvs = pl.buf("gqkv"); const size_t kvs_bytes = (size_t)N * T * 192 * sizeof(float);
+            ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_attn_fwd_bf16(qkv, 192, aoh, 64, N, T, st, kvs, kvs_bytes); }, K_ATTN, 4.0 * N * 4 * (double)T * T * 16));
         } else
             ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_attn_fwd(qkv, 192, ao, 64, lse, N, T, st); }, K_ATTN, 4.0 * N * 4 * (double)T * T * 16));
     }
