@@ -73,6 +73,12 @@ constexpr int W_BSZ = 16 * 4 * 32;                                              
 
 }  // namespace
 
+#ifndef SSIE_WINO_DMA_ROW_HI
+#define SSIE_WINO_DMA_ROW_HI 1      // transform row after which waves 4-7 issue the next step's DMA (waves 0-3: row 0); A/B builds: tools/build_variant.sh <name> WORK -DSSIE_WINO_DMA_ROW_HI=k
+#endif
+#ifndef SSIE_WINO_DMA_SPLIT
+#define SSIE_WINO_DMA_SPLIT 0       // 1: a wave's U pieces and halo pieces go out one transform row apart
+#endif
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // packed fp32 add / subtract as inline asm: hipcc splits float2 additions whose lanes are consumed one by one (by the MFMAs) into two v_add_f32, and every
@@ -219,10 +225,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned u_lane = (unsigned)(((lane >> 5) * p.Cout_pad + (lane & 31)) * 16);
 #define WN_RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, (int)(bytes), 0x00020000)
 #define WN_BLDS(rs, lptr, vo, so) __builtin_amdgcn_raw_ptr_buffer_load_lds((rs), (__attribute__((address_space(3))) void*)(lptr), 16, (int)(vo), (int)(so), 0, 0)
-#define WN_PREFETCH(CHUNK, N_, A0_, B0_, CO0_, BUF)                                                           \
+#define WN_PREFETCH(CHUNK, N_, A0_, B0_, CO0_, BUF, PART)                                                         \
     {                                                                                                         \
         f32x4* bbuf_ = Bs0 + (BUF) * W_BSZ;                                                                   \
-        if (UP) {                                                                                             \
+        if ((PART) == 2) {                                                                                    \
+        } else if (UP) {                                                                                      \
             const f32x4* wsrc_ = (const f32x4*)p.wpacked + (size_t)(CHUNK) * 64 * p.Cout_pad + (CO0_);        \
             _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                \
                 const int pc_ = q_ * 8 + wave;                    /* piece = two (xi, q) rows of 32 float4 */   \
@@ -238,7 +245,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const SrcSel s_ = SINGLE ? ssie_only_src(p) : ssie_pick_src(p, (CHUNK) * SSIE_CK);                    \
         const int vy0_ = (A0_) - 1, vx0_ = (B0_) - 1;                                                         \
         f32x4* abuf_ = As0 + (BUF) * W_HPB;                                                                   \
-        if (UP) {                                                                                             \
+        if ((PART) == 1) {                                                                                    \
+        } else if (UP) {                                                                                      \
             _Pragma("unroll") for (int i_ = 0; i_ < W_HPB / NTHR; ++i_) {                                     \
                 const int id_ = i_ * NTHR + tid;                                                              \
                 const int j_ = (id_ >= W_PLANE) + (id_ >= 2 * W_PLANE) + (id_ >= 3 * W_PLANE), r_ = id_ - j_ * W_PLANE; \
@@ -283,7 +291,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int n, a0, b0, co0;
     WN_DECODE(tile, n, a0, b0, co0)
     int gstep = 0;
-    WN_PREFETCH(0, n, a0, b0, co0, 0)
+    WN_PREFETCH(0, n, a0, b0, co0, 0, 0)
     int fetched = 0x7fffffff;
     ST_DECL
 
@@ -357,10 +365,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
                 // the next step's DMA is issued AFTER the first transform row's MFMAs: right behind the barrier all 8 waves would
                 // do address arithmetic (VALU = no MFMA) while the matrix pipe has nothing queued yet
-                if (i == 0) {
+                // Waves w and w + 4 share a SIMD.  An LDS-DMA instruction holds its wave at issue while the wave's previous pieces are
+                // in flight (measured: 340-550 cycles per piece in the bf16 kernels), and a wave stalled there issues no MFMAs - so the
+                // partners must not issue their nine pieces at the same time: waves 4-7 do it SSIE_WINO_DMA_ROW_HI transform rows
+                // later (-0.3 ms per train step against both at row 0), and with SSIE_WINO_DMA_SPLIT the U pieces and the halo pieces
+                // of a wave go out one row apart.
+                {
                     const bool more = step + 1 < nsteps;
-                    if (more) WN_PREFETCH(step + 1, n, a0, b0, co0, buf ^ 1)
-                    else if (ntile < total_tiles) WN_PREFETCH(0, nn, na0, nb0, nco0, buf ^ 1)
+                    const int r0 = wave >= 4 ? SSIE_WINO_DMA_ROW_HI : 0;
+                    if (!SSIE_WINO_DMA_SPLIT || UP) {
+                        if (i == r0) {
+                            if (more) WN_PREFETCH(step + 1, n, a0, b0, co0, buf ^ 1, 0)
+                            else if (ntile < total_tiles) WN_PREFETCH(0, nn, na0, nb0, nco0, buf ^ 1, 0)
+                        }
+                    } else {
+                        if (i == r0) {
+                            if (more) WN_PREFETCH(step + 1, n, a0, b0, co0, buf ^ 1, 1)
+                            else if (ntile < total_tiles) WN_PREFETCH(0, nn, na0, nb0, nco0, buf ^ 1, 1)
+                        }
+                        if (i == r0 + 1) {
+                            if (more) WN_PREFETCH(step + 1, n, a0, b0, co0, buf ^ 1, 2)
+                            else if (ntile < total_tiles) WN_PREFETCH(0, nn, na0, nb0, nco0, buf ^ 1, 2)
+                        }
+                    }
                 }
             }
             if (tid == 0 && step == 0 && nsteps > 1 && p.tile_counter)
