@@ -76,6 +76,9 @@ constexpr int W_BSZ = 16 * 4 * 32;                                              
 #ifndef SSIE_WINO_DMA_ROW_HI
 #define SSIE_WINO_DMA_ROW_HI 1      // transform row after which waves 4-7 issue the next step's DMA (waves 0-3: row 0); A/B builds: tools/build_variant.sh <name> WORK -DSSIE_WINO_DMA_ROW_HI=k
 #endif
+#ifndef SSIE_WINO_DMA_ROW_LO
+#define SSIE_WINO_DMA_ROW_LO 0
+#endif
 #ifndef SSIE_WINO_DMA_SPLIT
 #define SSIE_WINO_DMA_SPLIT 0       // 1: a wave's U pieces and halo pieces go out one transform row apart
 #endif
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 // of a wave go out one row apart.
                 {
                     const bool more = step + 1 < nsteps;
-                    const int r0 = wave >= 4 ? SSIE_WINO_DMA_ROW_HI : 0;
+                    const int r0 = wave >= 4 ? SSIE_WINO_DMA_ROW_HI : SSIE_WINO_DMA_ROW_LO;
                     if (!SSIE_WINO_DMA_SPLIT || UP) {
                         if (i == r0) {
                             if (more) WN_PREFETCH(step + 1, n, a0, b0, co0, buf ^ 1, 0)
