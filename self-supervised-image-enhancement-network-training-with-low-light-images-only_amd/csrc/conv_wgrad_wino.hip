@@ -4,7 +4,7 @@
 // the 36 of the direct sum.  A^T (3 x 4) = [[1,1,1,0],[0,1,-1,0],[0,1,1,1]], G (4 x 2) = [[1,0],[1/2,1/2],[1/2,-1/2],[0,1]],
 // B^T (4 x 4) = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,-1,0,1]] (checked against the direct correlation in fp64).  The sum over tiles is
 // linear, so the kernel accumulates dU[xi][ci][co] = sum_t V_t[xi][ci] H_t[xi][co] for the 16 transform positions xi - 16 GEMMs
-// with M = ci, N = co and K = TILES - and the 3 x 3 taps are formed once at the end (wgrad_wino_out_kernel, after the fixed-order
+// with M = ci, N = co and K = TILES - and the 3 x 3 taps are formed once per workgroup, from its accumulators, before the partial slab is written (the fixed-order
 // slab reduction), together with the 1/2 factors of G, which are left out of H.
 //   * NO operand re-layout: on v_mfma_f32_32x32x2_f32 the A operand wants (row = ci, k = tile) and the B operand (k = tile,
 //     column = co), i.e. lane l holds channel l % 32 of tile l / 32 of the pair.  That lane reads the 4 x 4 patch of ITS channel and
@@ -269,13 +269,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         if (wsub != 0) return;
     }
+    // dU -> the nine taps, per accumulator element (lane-local; once per workgroup): scale by the 1/2 factors left out of H, then
+    // A^T (.) A with A^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,1]].  The partial slabs are therefore [slice][tap 0..8][ci_pad][co_pad] - the
+    // layout of the direct kernel's - 9/16 of the bytes of a dU slab, and the fixed-order slice reduction writes dW directly.
+    float* dst0 = p.slabs + (((size_t)slice * 9) * p.ci_pad + ci0 + mi * 32) * p.co_pad + co0 + ni * 32 + li;
+    const size_t tstride = (size_t)p.ci_pad * p.co_pad;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        float* dst = p.slabs + (((size_t)slice * 16 + u) * p.ci_pad + ci0 + mi * 32) * p.co_pad + co0 + ni * 32 + li;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        float rr[3][4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-            dst[(size_t)i * p.co_pad] = acc[u][r];
+        for (int j = 0; j < 4; ++j) {
+            const float sj = (j == 1 || j == 2) ? 0.5f : 1.f;
+            const float u0 = acc[0 * 4 + j][r] * sj, u1 = acc[1 * 4 + j][r] * (0.5f * sj), u2 = acc[2 * 4 + j][r] * (0.5f * sj), u3 = acc[3 * 4 + j][r] * sj;
+            rr[0][j] = u0 + u1 + u2; rr[1][j] = u1 - u2; rr[2][j] = u1 + u2 + u3;
+        }
+        float* d = dst0 + (size_t)i * p.co_pad;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            d[(size_t)(k * 3 + 0) * tstride] = rr[k][0] + rr[k][1] + rr[k][2];
+            d[(size_t)(k * 3 + 1) * tstride] = rr[k][1] - rr[k][2];
+            d[(size_t)(k * 3 + 2) * tstride] = rr[k][1] + rr[k][2] + rr[k][3];
         }
     }
 }
@@ -285,36 +299,6 @@ template __global__ void conv_wgrad_wino_kernel<32, 64, false>(const WgradParams
 template __global__ void conv_wgrad_wino_kernel<64, 32, false>(const WgradParams);
 template __global__ void conv_wgrad_wino_kernel<32, 32, false>(const WgradParams);
 template __global__ void conv_wgrad_wino_kernel<64, 64, true>(const WgradParams);
-
-// dU[xi][ci][co] (summed over the slices by wgrad_reduce_kernel) -> dW[co][ci][3 x 3]: scale by the 1/2 factors left out of H, then
-// A^T (.) A with A^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,1]]
-__global__ __launch_bounds__(256) void wgrad_wino_out_kernel(const float* __restrict__ du, int Cin, int Cout, float* __restrict__ dst,
-                                                             long s_co, long s_ci, long s_t, int accumulate)
-{
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= Cin * Cout) return;
-    const int co = idx % Cout, ci = idx / Cout;
-    float u[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float sc = ((i == 1 || i == 2) ? 0.5f : 1.f) * ((j == 1 || j == 2) ? 0.5f : 1.f);
-            u[i][j] = du[((size_t)(i * 4 + j) * Cin + ci) * Cout + co] * sc;
-        }
-    float r[3][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { r[0][j] = u[0][j] + u[1][j] + u[2][j]; r[1][j] = u[1][j] - u[2][j]; r[2][j] = u[1][j] + u[2][j] + u[3][j]; }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float w3[3] = {r[k][0] + r[k][1] + r[k][2], r[k][1] - r[k][2], r[k][1] + r[k][2] + r[k][3]};
-#pragma unroll
-        for (int l = 0; l < 3; ++l) {
-            float* d = dst + co * s_co + ci * s_ci + (k * 3 + l) * s_t;
-            *d = accumulate ? *d + w3[l] : w3[l];
-        }
-    }
-}
 
 size_t ssie_wgrad_wino_lds_bytes(int cib, int cob)
 {
@@ -347,8 +331,3 @@ int ssie_launch_wgrad_wino(const WgradParams& p, hipStream_t st)
     return hipGetLastError() == hipSuccess ? 0 : 45;
 }
 
-int ssie_launch_wgrad_wino_out(const float* du, int Cin, int Cout, float* dst, long s_co, long s_ci, long s_t, int accumulate, hipStream_t st)
-{
-    hipLaunchKernelGGL(wgrad_wino_out_kernel, dim3((unsigned)((Cin * Cout + 255) / 256)), dim3(256), 0, st, du, Cin, Cout, dst, s_co, s_ci, s_t, accumulate);
-    return hipGetLastError() == hipSuccess ? 0 : 46;
-}

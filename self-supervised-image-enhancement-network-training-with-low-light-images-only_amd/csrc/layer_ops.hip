@@ -302,7 +302,7 @@ int ssie_make_wgrad(WgradParams& p, const SrcDesc& src, int N, int Hv, int Wv, i
     return 0;
 }
 
-size_t ssie_wgrad_slab_floats(const WgradParams& p) { return (size_t)p.nslices * (p.wino ? 16 : p.ntaps) * p.ci_pad * p.co_pad; }
+size_t ssie_wgrad_slab_floats(const WgradParams& p) { return (size_t)p.nslices * p.ntaps * p.ci_pad * p.co_pad; }
 
 // ---------------------------------------------------------------------------------------------
 // granular C-ABI
@@ -323,11 +323,10 @@ extern "C" size_t ssie_op_workspace_bytes(int cin, int cout, int k)
 {
     const int T = k * k;
     size_t packed = 4 * ssie_packed_floats(cin > cout ? cin : cout, cin > cout ? cin : cout, T);
-    // slabs: the direct kernels write kTargetWgs slices of one tap group; the Winograd weight gradient (3 x 3) writes
-    // kTargetWgs / 2 slices of 16 transform positions (8 per target workgroup < 9).  Behind them: the per-layer remainder and,
-    // for the Winograd path, the dU[16][ci][co] scratch of ssie_run_wgrad
+    // slabs: the direct kernels write kTargetWgs slices of one tap group, the Winograd weight gradient (3 x 3) kTargetWgs / 2
+    // slices of nine taps; behind them the per-layer remainder
     const int tg = T < SSIE_TG ? T : SSIE_TG;
-    size_t slabs = (size_t)kTargetWgs * tg * 64 * 64 + (size_t)(T > 16 ? T : 16) * ssie_round_up(cin, 64) * ssie_round_up(cout, 64);
+    size_t slabs = (size_t)kTargetWgs * tg * 64 * 64 + (size_t)T * ssie_round_up(cin, 64) * ssie_round_up(cout, 64);
     size_t partial = (size_t)256 * ssie_round_up(cout > cin ? cout : cin, 4);
     return (packed + slabs * 2 + partial) * sizeof(float) + 4096;
 }
@@ -497,17 +496,9 @@ int ssie_run_wgrad(const SrcDesc& x, int x_creal, int N, int Hv, int Wv, const f
     if (rc) return rc;
     const size_t need = ssie_wgrad_slab_floats(p);
     const size_t bneed = db ? (size_t)p.nslices * p.co_pad : 0;
-    const size_t du_floats = p.wino ? (size_t)16 * x_creal * gC : 0;     // Winograd: dU[16][ci][co] behind the slabs
-    if (need + bneed + du_floats > slab_cap_floats) return SSIE_E_WORKSPACE;   // checked BEFORE anything is enqueued
+    if (need + bneed > slab_cap_floats) return SSIE_E_WORKSPACE;   // checked BEFORE anything is enqueued
     p.bias_slabs = db ? slabs + need : nullptr;
     if (ssie_launch_wgrad(p, st)) return SSIE_E_LAUNCH;
-    if (p.wino) {
-        // slabs -> dU[16][ci][co] (fixed-order sum over the slices) -> the nine taps
-        float* du = slabs + need + bneed;
-        if (ssie_launch_wgrad_reduce(slabs, p.nslices, 16, p.ci_pad, p.co_pad, x_creal, gC, du, 1, gC, (long)x_creal * gC,
-                                     p.bias_slabs, db, 0, st, accumulate)) return SSIE_E_LAUNCH;
-        return ssie_launch_wgrad_wino_out(du, x_creal, gC, dw, s_co, s_ci, s_t, accumulate, st) ? SSIE_E_LAUNCH : 0;
-    }
     if (ssie_launch_wgrad_reduce(slabs, p.nslices, p.ntaps, p.ci_pad, p.co_pad, x_creal, gC, dw, s_co, s_ci, s_t,
                                  p.bias_slabs, db, accumulate, st)) return SSIE_E_LAUNCH;
     return 0;

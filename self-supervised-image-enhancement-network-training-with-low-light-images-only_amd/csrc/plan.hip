@@ -171,11 +171,9 @@ void build_buffers(Plan& pl)
     // bf16 inference path: bf16 copies of the tensors that also exist in fp32 (allocated in float units: C/2)
     alloc(pl, "xh", N, H, W, ssie_round_up(B, 8) / 2); alloc(pl, "RLh", N, H, W, ssie_round_up(B + 1, 8) / 2); alloc(pl, "aoh", N, H8, W8, 32);
     // scratch
-    // one slab area: kWgs slices of a 9-tap group over a 64 x 64 block (the Winograd weight gradient writes kWgs / 2 slices of 16
-    // transform positions: 8 per slice-pair < 9) + the per-layer remainder of the 9 x 9 / B+1-channel layers + the fused bias
-    // slabs + the Winograd dU[16][ci][co] scratch of the widest 3 x 3 layer (128 x 128, or 64 x (B+1))
-    const size_t du_max = (size_t)16 * 128 * (ssie_round_up(B + 1, 64) > 128 ? ssie_round_up(B + 1, 64) : 128);
-    pl.slab_cap = (size_t)kWgs * 9 * 64 * 64 + (size_t)81 * ssie_round_up(B + 1, 64) * 128 + (size_t)kWgs * ssie_round_up(B + 1, 64) + du_max;
+    // one slab area: kWgs slices of a 9-tap group over a 64 x 64 block (the Winograd weight gradient writes kWgs / 2 slices of nine
+    // taps) + the per-layer remainder of the 9 x 9 / B+1-channel layers + the fused bias slabs
+    pl.slab_cap = (size_t)kWgs * 9 * 64 * 64 + (size_t)81 * ssie_round_up(B + 1, 64) * 128 + (size_t)kWgs * ssie_round_up(B + 1, 64);
     pl.slab_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + pl.slab_cap, 64);
     pl.slab_off2 = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + pl.slab_cap, 64);
     pl.partial_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 256 * 256, 64);
@@ -382,8 +380,7 @@ struct Builder {
         if (rc) return rc;
         const size_t need = ssie_wgrad_slab_floats(p);
         const size_t bneed = with_bias ? (size_t)p.nslices * p.co_pad : 0;
-        const size_t du_floats = p.wino ? (size_t)16 * creal * L.cout : 0;
-        if (need + bneed + du_floats > pl.slab_cap) return SSIE_E_WORKSPACE;     // before any op of this layer is pushed
+        if (need + bneed > pl.slab_cap) return SSIE_E_WORKSPACE;     // before any op of this layer is pushed
         float* dw = pl.G + L.w + (size_t)ci_off * T;
         const long s_co = (long)L.cin * T;
         const float* slabs = pl.ws + soff;
@@ -395,14 +392,6 @@ struct Builder {
         char tag[96];
         snprintf(tag, sizeof(tag), "%swgrad ci%d co%d taps%d si%d %dx%d slices%d", p.wino ? "winograd " : "", creal, cout, T, stride, Ho, Wo, p.nslices);
         ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_wgrad(p, st); }, p.wino ? K_WGRAD_WINO : K_WGRAD, fl, tag, sl, SLAB_WRITE));
-        if (p.wino) {
-            // slabs -> dU[16][ci][co] (fixed-order sum over the slices; the fused bias gradient goes straight to its place) -> 9 taps;
-            // dU lives in the same slab area, so the tap extraction is a slab reader too
-            float* du = pl.ws + soff + need + bneed;
-            ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, p.nslices, 16, p.ci_pad, p.co_pad, creal, cout, du, 1, cout, (long)creal * cout, bslab, db, 0, st, 1); }, K_WGRAD_REDUCE, 0.0, "", sl, SLAB_READ));
-            ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_wino_out(du, creal, cout, dw, s_co, T, 1, 1, st); }, K_WGRAD_REDUCE, 0.0, "winograd wgrad: taps", sl, SLAB_READ));
-            return 0;
-        }
         ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, p.nslices, p.ntaps, p.ci_pad, p.co_pad, creal, cout, dw, s_co, T, 1, bslab, db, 1, st); }, K_WGRAD_REDUCE, 0.0, "", sl, SLAB_READ));
         return 0;
     }

@@ -96,7 +96,7 @@ struct WgradParams {
     int ci_blocks, co_blocks, tap_groups;
     int wsplit;             // waves sharing one (ci,co) tile pair = partial slabs written per workgroup (4 / tile pairs)
     int rows2;              // 9 x 9 only: tap_groups counts PAIRS of kernel rows, one wave pair per row (conv_wgrad_kernel SW = 4)
-    int wino;               // 1: Winograd F(3x3,2x2) kernel (conv_wgrad_wino.hip): slabs hold 16 transform positions instead of 9 taps
+    int wino;               // 1: Winograd F(3x3,2x2) kernel (conv_wgrad_wino.hip); its slabs hold the nine taps like the direct kernel's
 };
 
 struct PackDesc {
@@ -122,7 +122,6 @@ int ssie_launch_wgrad_reduce(const float* slabs, int nslices, int ntaps, int ci_
                              float* dst, long s_co, long s_ci, long s_t, const float* bias_slabs, float* db,
                              int accumulate, hipStream_t st, int accumulate_bias = -1);
 int ssie_launch_wgrad_wino(const WgradParams& p, hipStream_t st);                      // conv_wgrad_wino.hip
-int ssie_launch_wgrad_wino_out(const float* du, int Cin, int Cout, float* dst, long s_co, long s_ci, long s_t, int accumulate, hipStream_t st);
 int ssie_launch_colsum(const float* g, long npix, int cstride, int coff, int C, float* partial, int nblk,
                        float* dst, int accumulate, hipStream_t st);
 int ssie_launch_pack(const PackDesc& d, hipStream_t st);
