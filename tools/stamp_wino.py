@@ -9,9 +9,10 @@ from ssie_amd import build, hostlib as H
 
 def main():
     cin, cout, k, hw, N = (int(a) for a in (sys.argv[1:6] if len(sys.argv) > 5 else (64, 64, 3, 128, 32)))
-    out = "/tmp/libssie_stamp_wino.so"
+    extra = os.environ.get("SSIE_STAMP_FLAGS", "").split()          # e.g. -DSSIE_X_NOSTORE: ablation builds
+    out = "/tmp/libssie_stamp_wino" + "".join(f.replace("-D", "_") for f in extra) + ".so"
     if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(s) for s in build.sources()):
-        subprocess.check_call([build.hipcc(), *build.FLAGS, "-DSSIE_STAMP", "-shared", "-o", out, *build.sources()])
+        subprocess.check_call([build.hipcc(), *build.FLAGS, "-DSSIE_STAMP", *extra, "-shared", "-o", out, *build.sources()])
     L = C.CDLL(out)
     L.ssie_op_workspace_bytes.restype = C.c_size_t
     L.ssie_debug_set_wino_min_tiles(1)
