@@ -29,6 +29,7 @@ void ssie_debug_set_overlap(int on);                    /* [1] 0 = slab reductio
 void ssie_debug_set_fprop_min_tiles16(int v);           /* [256] launches with fewer 16x16 tiles use the 8x16 register-staged kernel */
 void ssie_debug_set_fprop_wide(int v);                  /* [1] 0 = no 16x32 tiles */
 void ssie_debug_set_fprop_wide_min_tiles(int v);        /* [512] */
+void ssie_debug_set_wgrad_reduce_wide_min(int v);       /* [64] slice count from which the slab reduction runs 16 slice groups per block (a huge value = never) */
 void ssie_debug_set_fft_chunk_mb(int mb);                /* [192] workspace chunk (MiB) of the three-pass Fourier loss (plans created afterwards) */
 void ssie_debug_set_attn_bf16_prepass(int v);           /* [1] 0 = the bf16 attention converts K / V per workgroup instead of once */
 void ssie_debug_set_bf16_conv9(int v);                  /* [1] 0 = the bf16 9x9 layer stays on the generic kernel */

@@ -576,16 +576,22 @@ template __global__ void conv_wgrad_kernel<64, 64, 9, 3>(const WgradParams);
 template __global__ void conv_wgrad_kernel<32, 64, 9, 4>(const WgradParams);
 
 // dst[co*s_co + ci*s_ci + t*s_t] (+)= sum_slices slab[slice][t][ci][co]; the trailing rows are the fused bias gradient
-// db[co] (+)= sum_slices bias_slab[slice][co].  Each thread owns 4 consecutive co (one 16-byte load per slice);
-// 64 output quads x 4 slice groups per block, fixed summation order (deterministic, identical on every rank).
+// db[co] (+)= sum_slices bias_slab[slice][co].  Each thread owns 4 consecutive co (one 16-byte load per slice) of a slice GROUP:
+// a block = OQ output quads x SG slice groups (SG = 256 / OQ), fixed summation order (deterministic, identical on every rank).
+// OQ = 16 / SG = 16 for the 256-slice launches: with 64 / 4 a 64 x 64 x 9 layer was 144 workgroups whose threads each walked 64
+// slabs that are 147 KB apart (eight batches of eight loads in flight: latency-bound, 1.9 TB/s); 576 workgroups of two batches
+// per thread run the same bytes in half the time.  (The slice reduction is NOT hidden by the side stream any more: SSIE_OVERLAP=0
+// and 1 time the same since the persistent convolution kernels leave it no CU to overlap on - it is paid in full.)
+template <int OQ>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int nslices, int ntaps, int ci_pad, int co_pad,
                                     int Cin, int Cout, float* __restrict__ dst, long s_co, long s_ci, long s_t,
                                     const float* __restrict__ bias_slabs, float* __restrict__ db, int accumulate, int accumulate_bias)
 {
-    __shared__ f32x4 red[4][64];
-    const int lo = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    constexpr int SG = 256 / OQ;
+    __shared__ f32x4 red[SG][OQ];
+    const int lo = threadIdx.x % OQ, sg = threadIdx.x / OQ;
     const int cq = (Cout + 3) / 4;                                 // channel quads per (tap, ci) row
-    const long idx = (long)blockIdx.x * 64 + lo;
+    const long idx = (long)blockIdx.x * OQ + lo;
     const long total = (long)ntaps * Cin * cq;
     const long total_b = total + (bias_slabs ? cq : 0);
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
@@ -598,22 +604,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         const float* sp = slabs + ((size_t)t * ci_pad + ci) * co_pad + co;
         // 8 independent loads in flight per thread (the slabs are 100+ KB apart: latency-, not bandwidth-bound otherwise)
         int s = sg;
-        for (; s + 28 < nslices; s += 32) {
+        for (; s + 7 * SG < nslices; s += 8 * SG) {
             f32x4 v[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = *(const f32x4*)(sp + (size_t)(s + 4 * q) * slab_sz);
+            for (int q = 0; q < 8; ++q) v[q] = *(const f32x4*)(sp + (size_t)(s + SG * q) * slab_sz);
             sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
         }
-        for (; s < nslices; s += 4) sum += *(const f32x4*)(sp + (size_t)s * slab_sz);
+        for (; s < nslices; s += SG) sum += *(const f32x4*)(sp + (size_t)s * slab_sz);
     } else if (idx < total_b) {
         is_b = true;
         co = (int)(idx - total) * 4;
-        for (int s = sg; s < nslices; s += 4) sum += *(const f32x4*)(bias_slabs + (size_t)s * co_pad + co);
+        for (int s = sg; s < nslices; s += SG) sum += *(const f32x4*)(bias_slabs + (size_t)s * co_pad + co);
     }
     red[sg][lo] = sum;
     __syncthreads();
     if (sg == 0 && (is_w || is_b)) {
-        const f32x4 tot = (red[0][lo] + red[1][lo]) + (red[2][lo] + red[3][lo]);
+        f32x4 tot = red[0][lo];
+#pragma unroll
+        for (int g = 1; g < SG; ++g) tot += red[g][lo];             // fixed order
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (co + k >= Cout) break;
@@ -622,6 +630,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         }
     }
 }
+template __global__ void wgrad_reduce_kernel<64>(const float*, int, int, int, int, int, int, float*, long, long, long, const float*, float*, int, int);
+template __global__ void wgrad_reduce_kernel<16>(const float*, int, int, int, int, int, int, float*, long, long, long, const float*, float*, int, int);
 
 // per-channel sums of G over all pixels (bias gradient of the transposed conv), two-stage & deterministic.
 // Stage 1: a thread owns one channel quad (float4) and every (256 / quads)-th pixel of the block's range, with four
@@ -901,15 +911,22 @@ int ssie_launch_wgrad(const WgradParams& p, hipStream_t st)
     return 21;
 }
 
+int ssie_wgrad_reduce_wide_min = 64;      // launches with at least this many slices: 16 output quads x 16 slice groups per block
+extern "C" void ssie_debug_set_wgrad_reduce_wide_min(int v) { ssie_wgrad_reduce_wide_min = v; }
 int ssie_launch_wgrad_reduce(const float* slabs, int nslices, int ntaps, int ci_pad, int co_pad, int Cin, int Cout,
                              float* dst, long s_co, long s_ci, long s_t, const float* bias_slabs, float* db,
                              int accumulate, hipStream_t st, int accumulate_bias)
 {
     const long cq = (Cout + 3) / 4;
     long total = (long)ntaps * Cin * cq + (bias_slabs ? cq : 0);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st,
-                       slabs, nslices, ntaps, ci_pad, co_pad, Cin, Cout, dst, s_co, s_ci, s_t, bias_slabs, db, accumulate,
-                       accumulate_bias < 0 ? accumulate : accumulate_bias);
+    if (nslices >= ssie_wgrad_reduce_wide_min)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st,
+                           slabs, nslices, ntaps, ci_pad, co_pad, Cin, Cout, dst, s_co, s_ci, s_t, bias_slabs, db, accumulate,
+                           accumulate_bias < 0 ? accumulate : accumulate_bias);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st,
+                           slabs, nslices, ntaps, ci_pad, co_pad, Cin, Cout, dst, s_co, s_ci, s_t, bias_slabs, db, accumulate,
+                           accumulate_bias < 0 ? accumulate : accumulate_bias);
     return hipGetLastError() == hipSuccess ? 0 : 25;
 }
 

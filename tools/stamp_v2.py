@@ -9,21 +9,22 @@ from ssie_amd import build, hostlib as H
 
 def main():
     cin, cout, k, hw, N = (int(a) for a in (sys.argv[1:6] if len(sys.argv) > 5 else (64, 64, 3, 128, 32)))
+    stride = int(sys.argv[6]) if len(sys.argv) > 6 else 1
     out = "/tmp/libssie_stamp_v2.so"
-    if not os.path.exists(out):
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(s) for s in build.sources()):
         subprocess.check_call([build.hipcc(), *build.FLAGS, "-DSSIE_STAMP", "-shared", "-o", out, *build.sources()])
     L = C.CDLL(out)
     L.ssie_op_workspace_bytes.restype = C.c_size_t
     dev = "cuda"
     cs = (cin + 3) // 4 * 4
     x = torch.randn(N, hw, hw, cs, device=dev); x[..., cin:] = 0; w = torch.randn(cout, cin, k, k, device=dev) * 0.05; b = torch.randn(cout, device=dev)
-    o = torch.zeros(N, hw, hw, cout, device=dev)
+    o = torch.zeros(N, hw // stride, hw // stride, cout, device=dev)
     ws = torch.zeros(L.ssie_op_workspace_bytes(cin, cout, k) // 4 + 1, device=dev)
     nwg = 256
     stamps = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
     arr = (H.SrcT * 1)(H.src_of(x, cs))
     def run():
-        return L.ssie_conv2d_fwd(arr, 1, N, hw, hw, H.ptr(w), cin, H.ptr(b), cout, k, 1, 1, None, None, H.ptr(o), cout, 0,
+        return L.ssie_conv2d_fwd(arr, 1, N, hw, hw, H.ptr(w), cin, H.ptr(b), cout, k, stride, 1, None, None, H.ptr(o), cout, 0,
                                  H.ptr(ws), C.c_size_t(ws.numel() * 4), None)
     rc = run(); assert rc == 0, f"ssie_conv2d_fwd rc={rc}"
     for _ in range(20):
