@@ -783,7 +783,9 @@ int run_ops(std::vector<Fn>& ops, hipStream_t st)
 }
 
 int g_fused_tail = 1;   // ssie_debug_set_fused_tail: 0 = inference runs feature_fusion / final_conv / compose as separate launches
-int g_overlap = 1;      // ssie_debug_set_overlap: 0 = everything in launch order on the caller's stream
+int g_overlap = 0;      // ssie_debug_set_overlap: 1 = the weight gradients' slab reductions on a side stream (run_ops_overlapped).  Default 0
+                        // since round 3: the persistent convolution kernels leave a side stream no CU to overlap on, and with the wider
+                        // reduction kernel launch order on one stream is 0.07 ms per step FASTER at 31 bands (equal at 256)
 
 // backward schedule with the slab reductions on the side stream:
 //   wgrad(slab b)   on st   : waits for the reduction that last read slab b, then records ev_w[b]

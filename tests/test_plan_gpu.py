@@ -173,6 +173,30 @@ def test_stagewise_parity(pkg, case, forced_kernels):
     assert not bad, "parity failures:\n" + "\n".join(bad)
 
 
+def test_side_stream_overlap_is_bit_identical(pkg):
+    """The slab reductions of the weight gradients can run on a side stream (ssie_debug_set_overlap(1): per-op slab flags, events
+    both ways); the default is launch order on the caller's stream.  Same kernels, same summation orders: the two executors must
+    give bit-identical gradients and losses (a missing slab dependency shows up as a wrong gradient, as it did in round 2)."""
+    H, _ = pkg
+    L = H.lib()
+    n, bands, h, w, coefs = 2, 31, 64, 64, O.JYU_COEFS
+    x = O.synthetic_patches(n, bands, h, w).cuda()
+    out = []
+    try:
+        for mode in (0, 1):
+            L.ssie_debug_set_overlap(mode)
+            plan, table, flat, gflat, P = build_plan(H, n, bands, h, w, coefs)
+            for _ in range(2):                              # twice: the second run reuses slab areas the first one filled
+                gflat.zero_()
+                plan.loss_fwd_bwd(x, backward=True)
+            torch.cuda.synchronize()
+            out.append((gflat.clone(), plan.loss_scalars().clone()))
+    finally:
+        L.ssie_debug_set_overlap(0)
+    assert torch.equal(out[0][0], out[1][0])
+    assert torch.equal(out[0][1], out[1][1])
+
+
 @pytest.mark.parametrize("case", ["b5_16", "b31_32", "b31_64"])
 def test_golden_reference_outputs(pkg, golden_dir, case):
     """HIP path vs the reference's own outputs (fixtures made by tests/golden/make_golden.py)."""
