@@ -707,7 +707,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16w_kernel(const ConvPara
 // sit in the vector-memory issue queue (76 KB per step against ~22 B/clk) with their MFMAs queued up behind - and another 6 500
 // in the barrier that follows a step that is shorter than the DMA's flight.  A stalled producer holds up nobody's MFMAs.
 // Static tile assignment (tile += gridDim.x), one tap group per chunk (<= 9 taps), so a step = one 32-channel chunk.
-template <int TGT, bool SINGLE, int NWC, bool RESW>
+template <int TGT, bool SINGLE, int NWC, bool RESW, bool ADD = false>
 __global__ __launch_bounds__(64 * (NWC + 4)) void conv_fprop_bf16ws_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -897,6 +897,7 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void conv_fprop_bf16ws_kernel(const
         const bool inside = a0 + TH <= p.Ho && b0 + TWW <= p.Wo && (a0 + TH - 1) * p.so + p.py < p.Hout && (b0 + TWW - 1) * p.so + p.px < p.Wout;
         if (inside) {
             unsigned short* tbase = (unsigned short*)p.out + ((size_t)(n * p.Hout + a0 * p.so + p.py) * p.Wout + b0 * p.so + p.px) * p.out_cstride + p.out_coff + co0;
+            const unsigned short* abase = (const unsigned short*)p.addsrc + (tbase - (unsigned short*)p.out);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -906,9 +907,13 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void conv_fprop_bf16ws_kernel(const
                         const f32x16& a = acc[m][c];
                         uint2 u[2];
 #pragma unroll
-                        for (int e = 0; e < 2; ++e)
-                            u[e] = make_uint2(ssie_pack2bf(fmaxf(a[4 * (g2 + e)], relu_lo), fmaxf(a[4 * (g2 + e) + 1], relu_lo)),
-                                              ssie_pack2bf(fmaxf(a[4 * (g2 + e) + 2], relu_lo), fmaxf(a[4 * (g2 + e) + 3], relu_lo)));
+                        for (int e = 0; e < 2; ++e) {
+                            f32x4 v = {fmaxf(a[4 * (g2 + e)], relu_lo), fmaxf(a[4 * (g2 + e) + 1], relu_lo), fmaxf(a[4 * (g2 + e) + 2], relu_lo), fmaxf(a[4 * (g2 + e) + 3], relu_lo)};
+                            // ADD: the residual (bf16, same geometry as the output) is added to the activated value, in fp32, before
+                            // rounding: this lane's own four channels of the group, i.e. the un-swapped 8-byte position
+                            if (ADD) v += ssie_unpack4bf(*(const uint2*)(abase + lane_off[m] - 4 * h + 32 * c + 8 * (g2 + e)));
+                            u[e] = ssie_pack4bf(v);
+                        }
                         *(uint4*)(tbase + lane_off[m] + 32 * c + 8 * g2) = ssie_pair_swap(u[0], u[1]);
                     }
         } else {                                    // edge tile: the same stores, per-position validity
@@ -924,9 +929,11 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void conv_fprop_bf16ws_kernel(const
                         const f32x16& a = acc[m][c];
                         uint2 u[2];
 #pragma unroll
-                        for (int e = 0; e < 2; ++e)
-                            u[e] = make_uint2(ssie_pack2bf(fmaxf(a[4 * (g2 + e)], relu_lo), fmaxf(a[4 * (g2 + e) + 1], relu_lo)),
-                                              ssie_pack2bf(fmaxf(a[4 * (g2 + e) + 2], relu_lo), fmaxf(a[4 * (g2 + e) + 3], relu_lo)));
+                        for (int e = 0; e < 2; ++e) {
+                            f32x4 v = {fmaxf(a[4 * (g2 + e)], relu_lo), fmaxf(a[4 * (g2 + e) + 1], relu_lo), fmaxf(a[4 * (g2 + e) + 2], relu_lo), fmaxf(a[4 * (g2 + e) + 3], relu_lo)};
+                            if (ADD && ok) v += ssie_unpack4bf(*(const uint2*)((const unsigned short*)p.addsrc + opix + co0 + 4 * h + 32 * c + 8 * (g2 + e)));
+                            u[e] = ssie_pack4bf(v);
+                        }
                         const uint4 v = ssie_pair_swap(u[0], u[1]);         // (every lane takes part in the swap: no branch around it)
                         if (ok) *(uint4*)(ob + 32 * c + 8 * g2) = v;
                     }
@@ -952,6 +959,7 @@ template __global__ void conv_fprop_bf16ws_kernel<1, true, 8, false>(const ConvP
 template __global__ void conv_fprop_bf16ws_kernel<9, false, 4, false>(const ConvParams);
 template __global__ void conv_fprop_bf16ws_kernel<9, true, 4, false>(const ConvParams);
 template __global__ void conv_fprop_bf16ws_kernel<9, true, 8, true>(const ConvParams);
+template __global__ void conv_fprop_bf16ws_kernel<9, true, 8, true, true>(const ConvParams);
 template __global__ void conv_fprop_bf16ws_kernel<9, true, 4, true>(const ConvParams);
 
 
@@ -1220,7 +1228,14 @@ int ssie_launch_fprop_bf16(const ConvParams& p_in, hipStream_t st)
         // layers that end in the lean epilogue (bf16 output, ReLU or none, no residual / second output, whole 32-channel groups)
         // with 9 taps or 1 run the wave-specialised kernel
         const bool lean = p.out_bf16 && !p.addsrc && !p.out2 && (p.Cout % 32) == 0 && p.act != ACT_SIGMOID;
-        if (ssie_bf16_ws >= 1 && ssie_bf16_resw && lean && p.ntaps == 9 && p.nsrc == 1 && p.nchunks <= 2 && p.co_blocks == 1 &&
+        // the same with a residual added to the activated value (deconv1-3 of the illumination net)
+        if (ssie_bf16_ws >= 1 && ssie_bf16_resw && p.out_bf16 && p.addsrc && !p.out2 && (p.Cout % 32) == 0 && p.act != ACT_SIGMOID &&
+            p.ntaps == 9 && p.nsrc == 1 && p.nchunks <= 2 && p.co_blocks == 1 && p.hp_h * p.hp_w * 4 <= 2560 && !p.tile_counter) {
+            static unsigned seen_ra = 0;
+            ssie_allow_full_lds((const void*)conv_fprop_bf16ws_kernel<9, true, 8, true, true>, seen_ra);
+            hipLaunchKernelGGL((conv_fprop_bf16ws_kernel<9, true, 8, true, true>), grid, dim3(768), lds, st, p);
+        }
+        else if (ssie_bf16_ws >= 1 && ssie_bf16_resw && lean && p.ntaps == 9 && p.nsrc == 1 && p.nchunks <= 2 && p.co_blocks == 1 &&
             p.hp_h * p.hp_w * 4 <= 2560 && !p.tile_counter) {
             static unsigned seen_rw[2] = {0, 0};
             ssie_allow_full_lds((const void*)conv_fprop_bf16ws_kernel<9, true, 8, true>, seen_rw[0]);
