@@ -34,6 +34,8 @@ void ssie_debug_set_fft_chunk_mb(int mb);                /* [192] workspace chun
 void ssie_debug_set_attn_bf16_prepass(int v);           /* [1] 0 = the bf16 attention converts K / V per workgroup instead of once */
 void ssie_debug_set_bf16_conv9(int v);                  /* [1] 0 = the bf16 9x9 layer stays on the generic kernel */
 void ssie_debug_set_bf16_conv9_min_tiles(int v);        /* [256] */
+void ssie_debug_set_bf16_ws_geo(int v);                 /* [1] 0 = bf16 stride-2 / transposed 64-channel layers stay on the eight-wave kernel */
+void ssie_debug_set_bf16_ws_geo_min_tiles(int v);       /* [256] */
 void ssie_debug_set_bf16_resw(int v);                   /* [1] bf16 single-source 3x3 layers of <= 64 input channels keep their packed weights in LDS (1 = 8 consumer waves, 2 = 4, 0 = off) */
 void ssie_debug_set_bf16_ws(int v);                     /* [3] bf16 16x32 layers: 0 = eight-wave kernel, 1 / 3 = wave-specialised (8 / 4 consumer waves + 4 producer waves), 2 = DMA interleaved between taps */
 void ssie_debug_set_fprop_tile16(int v);                /* [1] */

@@ -707,12 +707,16 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_bf16w_kernel(const ConvPara
 // sit in the vector-memory issue queue (76 KB per step against ~22 B/clk) with their MFMAs queued up behind - and another 6 500
 // in the barrier that follows a step that is shorter than the DMA's flight.  A stalled producer holds up nobody's MFMAs.
 // Static tile assignment (tile += gridDim.x), one tap group per chunk (<= 9 taps), so a step = one 32-channel chunk.
-template <int TGT, bool SINGLE, int NWC, bool RESW, bool ADD = false>
+// GEO: 0 = 16 x 32 output tile, input stride 1 (the wide geometry); 1 = 8 x 16 tile, input stride 2 (ssie_make_conv_bf16's stride-2
+// geometry, 17 x 33 halo); 2 = 16 x 16 tile, stride 1 (the transposed-convolution classes and other 64-channel layers)
+template <int TGT, bool SINGLE, int NWC, bool RESW, bool ADD = false, int GEO = 0>
 __global__ __launch_bounds__(64 * (NWC + 4)) void conv_fprop_bf16ws_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    constexpr int NT = 2, NWP = 4, BN = 64, TH = 16, TWW = 32, CKH = 32;
-    constexpr int RW = TH / NWC, MT = RW;           // a consumer wave owns RW tile rows = MT M-tiles of 2 rows x 16 columns
+    constexpr int NT = 2, NWP = 4, BN = 64, CKH = 32;
+    constexpr int TH = GEO == 1 ? 8 : 16, TWW = GEO == 0 ? 32 : 16, SI = GEO == 1 ? 2 : 1, MPR = TWW / 16;
+    constexpr int RW = TH / NWC, MT = RW / 2 * MPR;    // a consumer wave owns RW tile rows = MT M-tiles of 2 rows x 16 columns
+    static_assert(RW >= 2 && RW % 2 == 0, "a consumer wave needs whole M-tiles");
     constexpr int PTHR = 64 * NWP, NTHR = 64 * (NWC + NWP);
     constexpr int NAP = 10;                         // DMA rounds of the 256 producer lanes over the 18 x 34 x 4 halo slots
     constexpr int BSZ = SSIE_TG * 4 * BN;           // float4 per B buffer
@@ -765,7 +769,7 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void conv_fprop_bf16ws_kernel(const
         {                                                                                                     \
             const SrcSel s_ = SINGLE ? ssie_only_src(p) : ssie_pick_src(p, (CHUNK) * CKH);                    \
             const bool up_ = s_.sy != 1.f || s_.sx != 1.f;                                                    \
-            const int vy0_ = (A0_) + p.min_dy, vx0_ = (B0_) + p.min_dx;                                       \
+            const int vy0_ = (A0_) * SI + p.min_dy, vx0_ = (B0_) * SI + p.min_dx;                             \
             f32x4* abuf_ = As0 + (BUF) * HP4;                                                                 \
             const bool lean_ = !up_ && (s_.C & 31) == 0 && vy0_ >= 0 && vx0_ >= 0 && vy0_ + p.hp_h <= p.Hv && vx0_ + p.hp_w <= p.Wv; \
             if (lean_) {                                                                                      \
@@ -823,7 +827,7 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void conv_fprop_bf16ws_kernel(const
     // ---------------------------------------------------- consumers ----------------------------------------------------
     int pixbase[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) pixbase[m] = (RW * wave + 2 * (m >> 1) + (li >> 4)) * p.hp_w + 16 * (m & 1) + (li & 15);
+    for (int m = 0; m < MT; ++m) pixbase[m] = (RW * wave + 2 * (m / MPR) + (li >> 4)) * SI * p.hp_w + (16 * (m % MPR) + (li & 15)) * SI;
     // byte offset inside a halo buffer of (M-tile m, tap t, k-quad 0); k-quad 1 is the same address ^ 32 (slot index ^ 2)
     int aaddr[SSIE_TG][MT];
 #pragma unroll
@@ -838,7 +842,7 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void conv_fprop_bf16ws_kernel(const
     int lane_off[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
-        lane_off[m] = ((RW * wave + 2 * (m >> 1) + (li >> 4)) * p.so * p.Wout + (16 * (m & 1) + (li & 15)) * p.so) * p.out_cstride + 8 * h;
+        lane_off[m] = ((RW * wave + 2 * (m / MPR) + (li >> 4)) * p.so * p.Wout + (16 * (m % MPR) + (li & 15)) * p.so) * p.out_cstride + 8 * h;
 
     int gstep = 0;
     HT_DECL
@@ -920,7 +924,7 @@ __global__ __launch_bounds__(64 * (NWC + 4)) void conv_fprop_bf16ws_kernel(const
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 bool ok;
-                const size_t opix = ssie_epilogue_pos(p, n, a0 + RW * wave + 2 * (m >> 1), b0 + 16 * (m & 1), li, ok);
+                const size_t opix = ssie_epilogue_pos(p, n, a0 + RW * wave + 2 * (m / MPR), b0 + 16 * (m % MPR), li, ok);
                 unsigned short* ob = (unsigned short*)p.out + opix + co0 + 8 * h;
 #pragma unroll
                 for (int c = 0; c < NT; ++c)
@@ -960,6 +964,10 @@ template __global__ void conv_fprop_bf16ws_kernel<9, false, 4, false>(const Conv
 template __global__ void conv_fprop_bf16ws_kernel<9, true, 4, false>(const ConvParams);
 template __global__ void conv_fprop_bf16ws_kernel<9, true, 8, true>(const ConvParams);
 template __global__ void conv_fprop_bf16ws_kernel<9, true, 8, true, true>(const ConvParams);
+template __global__ void conv_fprop_bf16ws_kernel<9, true, 4, false, false, 1>(const ConvParams);      // stride-2 3 x 3
+template __global__ void conv_fprop_bf16ws_kernel<4, true, 4, false, false, 2>(const ConvParams);      // transposed-convolution classes
+template __global__ void conv_fprop_bf16ws_kernel<2, true, 4, false, false, 2>(const ConvParams);
+template __global__ void conv_fprop_bf16ws_kernel<1, true, 4, false, false, 2>(const ConvParams);
 template __global__ void conv_fprop_bf16ws_kernel<9, true, 4, true>(const ConvParams);
 
 
@@ -1185,6 +1193,9 @@ extern "C" void ssie_debug_set_bf16_ws(int v) { ssie_bf16_ws = v; }
 int ssie_bf16_conv9 = 1, ssie_bf16_conv9_min_tiles = 256;   // the 9 x 9 layer on conv9x9_bf16ws_kernel (16 x 32 tiles) from this many tiles on
 extern "C" void ssie_debug_set_bf16_conv9(int v) { ssie_bf16_conv9 = v; }
 extern "C" void ssie_debug_set_bf16_conv9_min_tiles(int v) { ssie_bf16_conv9_min_tiles = v; }
+int ssie_bf16_ws_geo = 1, ssie_bf16_ws_geo_min_tiles = 256;   // stride-2 / transposed 64-channel layers on the wave-specialised kernel
+extern "C" void ssie_debug_set_bf16_ws_geo(int v) { ssie_bf16_ws_geo = v; }
+extern "C" void ssie_debug_set_bf16_ws_geo_min_tiles(int v) { ssie_bf16_ws_geo_min_tiles = v; }
 int ssie_bf16_resw = 1;               // single-source 9-tap layers of <= 64 input channels: weights resident in LDS (1 = 8 consumer waves, 2 = 4; 0 = off)
 extern "C" void ssie_debug_set_bf16_resw(int v) { ssie_bf16_resw = v; }
 int ssie_launch_fprop_bf16(const ConvParams& p_in, hipStream_t st)
@@ -1269,6 +1280,26 @@ int ssie_launch_fprop_bf16(const ConvParams& p_in, hipStream_t st)
         if (stamp_this) { hipStreamSynchronize(st); void* z = nullptr; hipMemcpyToSymbol(HIP_SYMBOL(ssie_stamp_buf_h), &z, sizeof(void*)); }
 #endif
         return hipGetLastError() == hipSuccess ? 0 : 65;
+    }
+    {
+        // 64-channel-block layers of the other geometries on the wave-specialised kernel (4 consumer + 4 producer waves): the stride-2
+        // 3 x 3 layers (8 x 16 tiles) and the four parity classes of the transposed convolutions (16 x 16 tiles, 4 / 2 / 2 / 1 taps)
+        const bool lean = p.out_bf16 && !p.addsrc && !p.out2 && (p.Cout % 32) == 0 && p.act != ACT_SIGMOID;
+        const size_t tiles = (size_t)p.N * p.tiles_y * p.tiles_x * p.co_blocks;
+        const dim3 grid((unsigned)(tiles < 256 ? tiles : 256));
+        if (ssie_bf16_ws_geo && ssie_bf16_ws >= 1 && lean && nt == 2 && p.nsrc == 1 && p.hp_h * p.hp_w * 4 <= 2560 && !p.tile_counter && p.tw == 16 &&
+            tiles >= (size_t)ssie_bf16_ws_geo_min_tiles) {
+#define WSG_LAUNCH(TG_, GEO_, K_)                                                                             \
+            { static unsigned seen_g = 0;                                                                     \
+              ssie_allow_full_lds((const void*)conv_fprop_bf16ws_kernel<TG_, true, 4, false, false, GEO_>, seen_g); \
+              hipLaunchKernelGGL((conv_fprop_bf16ws_kernel<TG_, true, 4, false, false, GEO_>), grid, dim3(512), lds, st, p); \
+              return hipGetLastError() == hipSuccess ? 0 : 67; }
+            if (p.th == 8 && p.si == 2 && p.ntaps == 9) WSG_LAUNCH(9, 1, 0)
+            if (p.th == 16 && p.si == 1 && p.ntaps == 4) WSG_LAUNCH(4, 2, 1)
+            if (p.th == 16 && p.si == 1 && p.ntaps == 2) WSG_LAUNCH(2, 2, 2)
+            if (p.th == 16 && p.si == 1 && p.ntaps == 1) WSG_LAUNCH(1, 2, 3)
+#undef WSG_LAUNCH
+        }
     }
     if (p.th == 8) return nt == 2 ? launch_h_t<2, 5, 8>(p, lds, st) : 63;
     if (p.th != 16) return 64;

@@ -48,7 +48,7 @@ def lib():
     # dev switches (include/ssie_debug.h); unset = the library's defaults
     for env, fn in (("SSIE_OVERLAP", "ssie_debug_set_overlap"), ("SSIE_MIN_TILES16", "ssie_debug_set_fprop_min_tiles16"),
                     ("SSIE_WGRAD_SLIDING", "ssie_debug_set_wgrad_sliding"), ("SSIE_V2_STRIDE2", "ssie_debug_set_fprop_v2_stride2"),
-                    ("SSIE_WIDE", "ssie_debug_set_fprop_wide"), ("SSIE_BF16_WS", "ssie_debug_set_bf16_ws"), ("SSIE_BF16_RESW", "ssie_debug_set_bf16_resw"), ("SSIE_BF16_CONV9", "ssie_debug_set_bf16_conv9"), ("SSIE_ATTN_PREPASS", "ssie_debug_set_attn_bf16_prepass"), ("SSIE_FFT_CHUNK_MB", "ssie_debug_set_fft_chunk_mb"), ("SSIE_REDUCE_WIDE_MIN", "ssie_debug_set_wgrad_reduce_wide_min"), ("SSIE_FFT_GROUPED", "ssie_debug_set_fft_grouped"),
+                    ("SSIE_WIDE", "ssie_debug_set_fprop_wide"), ("SSIE_BF16_WS", "ssie_debug_set_bf16_ws"), ("SSIE_BF16_RESW", "ssie_debug_set_bf16_resw"), ("SSIE_BF16_WS_GEO", "ssie_debug_set_bf16_ws_geo"), ("SSIE_BF16_CONV9", "ssie_debug_set_bf16_conv9"), ("SSIE_ATTN_PREPASS", "ssie_debug_set_attn_bf16_prepass"), ("SSIE_FFT_CHUNK_MB", "ssie_debug_set_fft_chunk_mb"), ("SSIE_REDUCE_WIDE_MIN", "ssie_debug_set_wgrad_reduce_wide_min"), ("SSIE_FFT_GROUPED", "ssie_debug_set_fft_grouped"),
                     ("SSIE_LOSS_CHUNKED", "ssie_debug_set_loss_chunked"), ("SSIE_LOSS_CHUNK_LPP", "ssie_debug_set_loss_chunk_lpp"), ("SSIE_LOSS_GENERIC", "ssie_debug_set_loss_generic"), ("SSIE_V2_SPLIT", "ssie_debug_set_fprop_v2_split")):
         if os.environ.get(env) is not None:
             getattr(L, fn)(int(os.environ[env]))

@@ -39,9 +39,11 @@ def wide_tiles(H, request):
     if request.param == "tile16x32":
         L.ssie_debug_set_fprop_wide_min_tiles(1)
         L.ssie_debug_set_bf16_conv9_min_tiles(1)
+        L.ssie_debug_set_bf16_ws_geo_min_tiles(1)
     yield request.param
     L.ssie_debug_set_fprop_wide_min_tiles(512)
     L.ssie_debug_set_bf16_conv9_min_tiles(256)
+    L.ssie_debug_set_bf16_ws_geo_min_tiles(256)
 
 
 @pytest.mark.parametrize("n,bands,h,w", [(2, 31, 64, 64), (1, 31, 50, 38), (1, 31, 136, 200), (1, 7, 32, 32)])
