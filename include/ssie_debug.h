@@ -26,6 +26,7 @@ int ssie_plan_num_ops(void* plan, int* counts3);
 
 /* launch heuristics */
 void ssie_debug_set_overlap(int on);                    /* [0] 1 = slab reductions of the weight gradients on a side stream; 0 = launch order on the caller's stream */
+void ssie_debug_set_graph(int on);                      /* [0] 1 = ssie_plan_loss_fwd_bwd (with backward) replays one hipGraph per plan behind the ingest */
 void ssie_debug_set_fprop_min_tiles16(int v);           /* [256] launches with fewer 16x16 tiles use the 8x16 register-staged kernel */
 void ssie_debug_set_fprop_wide(int v);                  /* [1] 0 = no 16x32 tiles */
 void ssie_debug_set_fprop_wide_min_tiles(int v);        /* [512] */

@@ -75,10 +75,14 @@ struct Plan {
     // alternate between two slab areas so that a reduction only has to finish before the wgrad AFTER the next one
     int slab_seq = 0;
     hipStream_t side = nullptr;
+    // hipGraph of one train step (ssie_debug_set_graph): captured on cap_stream at the second call, replayed on the caller's stream
+    hipStream_t cap_stream = nullptr; hipGraphExec_t gexec = nullptr; int train_calls = 0; bool graph_failed = false, use_graph = false;
     hipEvent_t ev_w[2] = {nullptr, nullptr}, ev_r[2] = {nullptr, nullptr};
     ~Plan() {
         for (int i = 0; i < 2; ++i) { if (ev_w[i]) hipEventDestroy(ev_w[i]); if (ev_r[i]) hipEventDestroy(ev_r[i]); }
         if (side) hipStreamDestroy(side);
+        if (gexec) hipGraphExecDestroy(gexec);
+        if (cap_stream) hipStreamDestroy(cap_stream);
     }
 
     float* buf(const char* n) { return ws + bufs.at(n).off; }
@@ -710,6 +714,9 @@ int check_slab_flags(const std::vector<Fn>& ops);
 
 int build_all(Plan& pl, bool dry)
 {
+    // the op lists are rebuilt (new coefficients, new buffers): a captured step graph holds the old launches
+    if (pl.gexec) { hipGraphExecDestroy(pl.gexec); pl.gexec = nullptr; }
+    pl.train_calls = 0;
     Builder b(pl, dry);
     pl.fwd.clear(); pl.pass2.clear(); pl.lossbwd.clear(); pl.slab_seq = 0;
     CK(build_decomposition_fwd(b, pl.fwd, "x", 1));
@@ -782,6 +789,7 @@ int run_ops(std::vector<Fn>& ops, hipStream_t st)
     return 0;
 }
 
+int g_graph = 0;        // ssie_debug_set_graph: 1 = the train step behind the ingest is replayed as one hipGraph (ssie_plan_loss_fwd_bwd)
 int g_fused_tail = 1;   // ssie_debug_set_fused_tail: 0 = inference runs feature_fusion / final_conv / compose as separate launches
 int g_overlap = 0;      // ssie_debug_set_overlap: 1 = the weight gradients' slab reductions on a side stream (run_ops_overlapped).  Default 0
                         // since round 3: the persistent convolution kernels leave a side stream no CU to overlap on, and with the wider
@@ -870,6 +878,16 @@ extern "C" void* ssie_plan_create(int N, int bands, int H, int W, const float* c
 }
 
 extern "C" void ssie_debug_set_overlap(int on) { g_overlap = on; }
+extern "C" void ssie_debug_set_graph(int on) { g_graph = on; }
+// product API (include/ssie_hip.h): replay this plan's train step as one hipGraph from its third call on
+extern "C" int ssie_plan_set_graph(void* h, int on)
+{
+    Plan* pl = (Plan*)h;
+    if (!pl) return SSIE_E_ARG;
+    pl->use_graph = on != 0;
+    if (!on && pl->gexec) { hipGraphExecDestroy(pl->gexec); pl->gexec = nullptr; }
+    return 0;
+}
 extern "C" void ssie_debug_set_spectral9(int on) { g_spectral9 = on; }
 extern "C" void ssie_debug_set_skinny_final(int on) { g_skinny_final = on; }   // takes effect for plans created afterwards
 extern "C" void ssie_debug_set_fused_tail(int on) { g_fused_tail = on; }     // takes effect for plans bound afterwards
@@ -990,6 +1008,36 @@ extern "C" int ssie_plan_loss_fwd_bwd(void* h, const float* x, const long* strid
     if (!ssie_fft_supported(pl->H, pl->W)) return SSIE_E_SHAPE;
     if (with_backward && !pl->G) return SSIE_E_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (with_backward && (g_graph || pl->use_graph) && !g_overlap && !pl->graph_failed) {
+        // One hipGraph for everything behind the ingest (weight packing, both forward passes, losses, backward): the op lists are
+        // fixed per plan and every pointer in them belongs to the plan, so the step is captured ONCE (at the second call: the first
+        // one has run every launcher's one-time hipFuncSetAttribute) on a stream of the plan's own - the caller's may be the null
+        // stream, which cannot be captured - and replayed on the caller's stream.
+        CK(ingest(pl, x, strides4, st));
+        if (!pl->gexec && pl->train_calls >= 1) {
+            hipGraph_t graph = nullptr;
+            bool ok = pl->cap_stream || hipStreamCreateWithFlags(&pl->cap_stream, hipStreamNonBlocking) == hipSuccess;
+            ok = ok && hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                int rc = pack_all(pl, pl->cap_stream);
+                if (!rc) rc = run_ops(pl->fwd, pl->cap_stream);
+                if (!rc) rc = run_ops(pl->pass2, pl->cap_stream);
+                if (!rc && hipMemsetAsync(pl->G, 0, pl->nparam_floats * 4, pl->cap_stream) != hipSuccess) rc = SSIE_E_LAUNCH;
+                if (!rc) rc = run_ops(pl->lossbwd, pl->cap_stream);
+                const bool ended = hipStreamEndCapture(pl->cap_stream, &graph) == hipSuccess;
+                ok = !rc && ended && graph && hipGraphInstantiate(&pl->gexec, graph, nullptr, nullptr, 0) == hipSuccess;
+                if (graph) hipGraphDestroy(graph);
+            }
+            if (!ok) { pl->graph_failed = true; pl->gexec = nullptr; (void)hipGetLastError(); }
+        }
+        if (pl->gexec) { ++pl->train_calls; return hipGraphLaunch(pl->gexec, st) == hipSuccess ? 0 : SSIE_E_LAUNCH; }
+        ++pl->train_calls;
+        CK(pack_all(pl, st));
+        CK(run_ops(pl->fwd, st));
+        CK(run_ops(pl->pass2, st));
+        if (hipMemsetAsync(pl->G, 0, pl->nparam_floats * 4, st) != hipSuccess) return SSIE_E_LAUNCH;
+        return run_ops(pl->lossbwd, st);
+    }
     CK(pack_all(pl, st));
     CK(ingest(pl, x, strides4, st));
     CK(run_ops(pl->fwd, st));

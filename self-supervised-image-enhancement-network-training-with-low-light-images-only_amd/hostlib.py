@@ -46,7 +46,7 @@ def lib():
     L.ssie_version.restype = C.c_char_p
     L.ssie_op_workspace_bytes.restype = C.c_size_t
     # dev switches (include/ssie_debug.h); unset = the library's defaults
-    for env, fn in (("SSIE_OVERLAP", "ssie_debug_set_overlap"), ("SSIE_MIN_TILES16", "ssie_debug_set_fprop_min_tiles16"),
+    for env, fn in (("SSIE_OVERLAP", "ssie_debug_set_overlap"), ("SSIE_GRAPH", "ssie_debug_set_graph"), ("SSIE_MIN_TILES16", "ssie_debug_set_fprop_min_tiles16"),
                     ("SSIE_WGRAD_SLIDING", "ssie_debug_set_wgrad_sliding"), ("SSIE_V2_STRIDE2", "ssie_debug_set_fprop_v2_stride2"),
                     ("SSIE_WIDE", "ssie_debug_set_fprop_wide"), ("SSIE_BF16_WS", "ssie_debug_set_bf16_ws"), ("SSIE_BF16_RESW", "ssie_debug_set_bf16_resw"), ("SSIE_BF16_WS_GEO", "ssie_debug_set_bf16_ws_geo"), ("SSIE_BF16_CONV9", "ssie_debug_set_bf16_conv9"), ("SSIE_ATTN_PREPASS", "ssie_debug_set_attn_bf16_prepass"), ("SSIE_FFT_CHUNK_MB", "ssie_debug_set_fft_chunk_mb"), ("SSIE_REDUCE_WIDE_MIN", "ssie_debug_set_wgrad_reduce_wide_min"), ("SSIE_FFT_GROUPED", "ssie_debug_set_fft_grouped"),
                     ("SSIE_LOSS_CHUNKED", "ssie_debug_set_loss_chunked"), ("SSIE_LOSS_CHUNK_LPP", "ssie_debug_set_loss_chunk_lpp"), ("SSIE_LOSS_GENERIC", "ssie_debug_set_loss_generic"), ("SSIE_V2_SPLIT", "ssie_debug_set_fprop_v2_split")):
@@ -195,6 +195,7 @@ def _proto():
                                        C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.ssie_plan_buffer.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
     L.ssie_plan_set_coefs.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.ssie_plan_set_graph.argtypes = [C.c_void_p, C.c_int]
     L.ssie_plan_bind.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ssie_plan_enhance_fwd.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_long), C.c_void_p]
     L.ssie_plan_enhance_fwd_bf16.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_long), C.c_void_p]
@@ -262,6 +263,10 @@ class Plan:
                 self.L.ssie_plan_destroy(self.h); self.h = None
         except Exception:
             pass
+
+    def set_graph(self, on: bool):
+        """replay the train step behind the input conversion as one hipGraph (ssie_plan_set_graph)"""
+        check(self.L.ssie_plan_set_graph(self.h, int(bool(on))), "ssie_plan_set_graph")
 
     def set_coefs(self, coefs: dict):
         cf = (C.c_float * 8)(*[float(coefs[k]) for k in COEF_ORDER])

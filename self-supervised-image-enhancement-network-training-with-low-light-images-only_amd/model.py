@@ -13,6 +13,8 @@ all-reduce per step (`train_step`).
 """
 from __future__ import annotations
 
+import os
+
 import math
 from collections import OrderedDict
 
@@ -245,6 +247,7 @@ class LowLightEnhance(nn.Module):
             while len(self._plans) >= self.max_cached_plans:
                 self._plans.pop(next(iter(self._plans)))
             plan = H.Plan(x.shape[0], self.input_channels, x.shape[2], x.shape[3], self.coefs(), self._flat, self._gflat)
+            plan.set_graph(os.environ.get("SSIE_GRAPH", "1") != "0")       # train steps of this plan replay one hipGraph
             self._plans[key] = plan
             plan._coefs = tuple(self.coefs().values())
         else:

@@ -37,6 +37,24 @@ def make_net(M, bands, coefs=O.JYU_COEFS, **kw):
     return net.to("cuda")
 
 
+def test_graph_replay_is_bit_identical(M, monkeypatch):
+    """A plan made by the module replays its train step as ONE hipGraph from the third call on (ssie_plan_set_graph; SSIE_GRAPH=0
+    turns it off).  Same kernels in the same order: parameters and losses after five steps must be bit-identical to the eager
+    launches; new loss coefficients rebuild the op lists and must drop the captured graph."""
+    res = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SSIE_GRAPH", flag)
+        net = make_net(M, 31)
+        x = O.synthetic_patches(2, 31, 64, 64).cuda()
+        scal = [net.train_step(x).clone() for _ in range(5)]
+        net.c_loss_fourier = 0.25                                   # coefficient change between steps (set_coefs -> rebuild)
+        scal += [net.train_step(x).clone() for _ in range(3)]
+        torch.cuda.synchronize()
+        res.append((torch.stack(scal), net._flat.clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
+
+
 def test_forward_returns_owned_tensors(M):
     net = make_net(M, 5)
     x1 = O.synthetic_patches(1, 5, 16, 16, seed=1).cuda(); x2 = O.synthetic_patches(1, 5, 16, 16, seed=2).cuda()
