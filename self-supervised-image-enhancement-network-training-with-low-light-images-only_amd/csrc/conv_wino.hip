@@ -19,6 +19,7 @@
 //   lane's float4 are the 4 MFMAs of a (xi, N-half).   B operand: lane = channel l%16 of the half, same quad g.
 //   D (16 x 16): lane l = channel l%16, registers r = tile columns 4g + r.
 #include "conv_device.h"
+#include <type_traits>
 
 __device__ f32x4 wino_zero_page[4];   // zero-initialised: source of padding slots
 
@@ -75,6 +76,9 @@ constexpr int W_BSZ = 16 * 4 * 32;                                              
 
 #ifndef SSIE_WINO_DMA_ROW_HI
 #define SSIE_WINO_DMA_ROW_HI 1      // transform row after which waves 4-7 issue the next step's DMA (waves 0-3: row 0); A/B builds: tools/build_variant.sh <name> WORK -DSSIE_WINO_DMA_ROW_HI=k
+#endif
+#ifndef SSIE_WINO_ZEROC
+#define SSIE_WINO_ZEROC 1
 #endif
 #ifndef SSIE_WINO_DMA_ROW_LO
 #define SSIE_WINO_DMA_ROW_LO 0
@@ -300,17 +304,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     while (tile < total_tiles) {
         f32x4 acc[16][2];
+#if !SSIE_WINO_ZEROC
 #pragma unroll
         for (int x = 0; x < 16; ++x)
 #pragma unroll
             for (int c = 0; c < 2; ++c) acc[x][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
         float bv[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) bv[c] = (p.bias && co0 + 16 * c + tx < p.Cout) ? p.bias[co0 + 16 * c + tx] : 0.f;
         int ntile = 0x7fffffff;
         int nn = n, na0 = a0, nb0 = b0, nco0 = co0;
 
-        for (int step = 0; step < nsteps; ++step, ++gstep) {
+        // SSIE_WINO_ZEROC: the first K step of a tile is its own instantiation of the step body whose first MFMA per accumulator takes a
+        // zero C operand - the 128 accumulator clears per tile and wave go away (vector instructions on the MFMA's issue slot)
+        auto step_body = [&](auto first_c, const int step) {
+            constexpr bool FIRST = SSIE_WINO_ZEROC && decltype(first_c)::value;
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
             const int buf = gstep & 1;
             if (tid == 0) {
                 if (nsteps == 1 || !p.tile_counter) {
@@ -362,8 +372,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     if (xi < 15) { bfn0 = Bl[((xi + 1) * 4) * 32]; bfn1 = Bl[((xi + 1) * 4) * 32 + 16]; }
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        acc[xi][0] = MFMA16(v[j][c >> 1][c & 1], bf0[c], acc[xi][0]);
-                        acc[xi][1] = MFMA16(v[j][c >> 1][c & 1], bf1[c], acc[xi][1]);
+                        acc[xi][0] = MFMA16(v[j][c >> 1][c & 1], bf0[c], (FIRST && c == 0) ? zero4 : acc[xi][0]);
+                        acc[xi][1] = MFMA16(v[j][c >> 1][c & 1], bf1[c], (FIRST && c == 0) ? zero4 : acc[xi][1]);
                     }
                 }
                 // the next step's DMA is issued AFTER the first transform row's MFMAs: right behind the barrier all 8 waves would
@@ -396,7 +406,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (tid == 0 && step == 0 && nsteps > 1 && p.tile_counter)
                 fetched = (int)gridDim.x + atomicAdd(p.tile_counter, 1);
             ST_ACC(7);
-        }
+        };
+#if SSIE_WINO_ZEROC
+        step_body(std::true_type{}, 0); ++gstep;
+        for (int step = 1; step < nsteps; ++step, ++gstep) step_body(std::false_type{}, step);
+#else
+        for (int step = 0; step < nsteps; ++step, ++gstep) step_body(std::false_type{}, step);
+#endif
 
         // output transform (lane-local) + epilogue: one pass of 16 outputs per 16-channel half
         {
