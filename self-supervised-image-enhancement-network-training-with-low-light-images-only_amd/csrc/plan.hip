@@ -457,6 +457,9 @@ struct Builder {
         ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_spec_fft(gp, gcs, 64, 2 * N, H, W, 0, Gn, 0, 2 * Mt, st); }, K_SPEC, 0.0, "spectral 9x9: fft grad (tiles)"));
         ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_spec_wgrad(Xf, Gn, dWs, 2 * Mt, Kp, ns, 64, B, dw, st); }, K_SPEC,
                          2.0 * 2 * N * H * W * 64.0 * B * 81, "spectral 9x9: wgrad"));
+        // the layer's bias gradient from the DC bins of the same spectra (instead of a column-sum pass over the gradient tensor)
+        float* part = pl.ws + pl.partial_off; float* db = pl.G + L.b;
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_spec_bias(Gn, 2 * Mt, part, db, 1, st); }, K_COLSUM, 0.0, "spectral 9x9: bias gradient (DC bins)"));
     }
 
     void upadj(std::vector<Fn>& ops, const char* src, int Hv, int Wv, const char* dst, int accumulate)
@@ -622,7 +625,7 @@ int build_decomposition_bwd(Builder& b, std::vector<Fn>& ops, const char* xin, i
     CK(b.dgrad(ops, L2, 2, G2.c_str(), 0, 0, 64, G1.c_str(), c1.c_str(), MASK_RELU, 1));
     if (wg) CK(b.wgrad(ops, L1, 1, b.src("sh_1", 64, H, W), 64, H, W, 0, "G1", 0, true, 2));
     CK(b.dgrad(ops, L1, 1, G1.c_str(), 0, 0, 64, Gsh.c_str(), nullptr, 0, 0));
-    if (wg && pl.spectral) { b.spec_wgrad(ops, Ls, "Gsh"); b.bias_grad(ops, Ls, "Gsh", 0, 2); }
+    if (wg && pl.spectral) b.spec_wgrad(ops, Ls, "Gsh");       // (incl. the bias gradient)
     else if (wg) CK(b.wgrad(ops, Ls, 1, b.src("x", pl.CX, H, W), pl.B, H, W, 0, "Gsh", 0, true, 2));
     if (wg) CK(b.wgrad(ops, L0, 1, b.src("x", pl.CX, H, W), pl.B, H, W, 0, "G0", 0, true, 2));
     if (input_grad) {

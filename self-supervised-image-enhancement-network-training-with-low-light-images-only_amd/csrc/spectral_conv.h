@@ -21,3 +21,5 @@ int ssie_launch_spec_weights(const float* w, int Cout, int Cin, int Kp, int Np, 
 int ssie_launch_spec_gemm(const float2* A, int Ma, int ma0, const float2* B, float2* C, int Mc, int mc0, int M, int Kp, int Np, hipStream_t st);
 // dw (Cout = 64, Cin, 9, 9) += correlation of the gradient tiles with the input windows; dWs = (nslices * NF + 9 * 17) * Kp * 64 complex scratch
 int ssie_launch_spec_wgrad(const float2* Xf, const float2* Gf, float2* dWs, int M, int Kp, int nslices, int Cout, int Cin, float* dw, hipStream_t st);
+// db[co] (+)= sum over all pixels of the gradient whose zero-padded tile spectra are Gn[M tiles][f][64] (the DC bins); partial: (M + 63) / 64 * 64 floats
+int ssie_launch_spec_bias(const float2* Gn, int M, float* partial, float* db, int accumulate, hipStream_t st);

@@ -556,6 +556,34 @@ int ssie_launch_spec_weights(const float* w, int Cout, int Cin, int Kp, int Np, 
     return hipGetLastError() == hipSuccess ? 0 : 95;
 }
 
+// Bias gradient of the 9 x 9 layer from the spectra the weight gradient already holds: the zero-padded 24 x 24 tiles of the output
+// gradient partition the image, so sum_pixels g[co] = sum_tiles Re G^[tile][f = 0][co] (the DC bin of an un-normalised transform is
+// the tile's sum).  Stage 1: a block sums 64 tiles (4 parts x 16 tiles per thread, fixed order); stage 2: colsum_final_kernel over
+// the blocks.  Replaces a colsum pass over the whole 2N x H x W x 64 gradient tensor (268 MB, 53 us at N = 32).
+__global__ __launch_bounds__(256) void spec_bias_partial_kernel(const float2* __restrict__ Gn, int M, float* __restrict__ partial)
+{
+    __shared__ float red[4][64];
+    const int co = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int m0 = blockIdx.x * 64;
+    float s = 0.f;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int m = m0 + part + 4 * i;
+        if (m < M) s += Gn[(size_t)m * NF * 64 + co].x;
+    }
+    red[part][co] = s;
+    __syncthreads();
+    if (part == 0) partial[(size_t)blockIdx.x * 64 + co] = (red[0][co] + red[1][co]) + (red[2][co] + red[3][co]);
+}
+__global__ void colsum_final_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ dst, int accumulate);   // conv_kernels.hip
+int ssie_launch_spec_bias(const float2* Gn, int M, float* partial, float* db, int accumulate, hipStream_t st)
+{
+    const int nblk = (M + 63) / 64;
+    hipLaunchKernelGGL(spec_bias_partial_kernel, dim3(nblk), dim3(256), 0, st, Gn, M, partial);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(64), dim3(256), 0, st, (const float*)partial, nblk, 64, db, accumulate);
+    return hipGetLastError() == hipSuccess ? 0 : 101;
+}
+
 int ssie_launch_spec_gemm(const float2* A, int Ma, int ma0, const float2* B, float2* C, int Mc, int mc0, int M, int Kp, int Np, hipStream_t st)
 {
     if (Kp % 8 || Np % 32) return 96;
