@@ -97,14 +97,29 @@ __global__ __launch_bounds__(256) void spec_fft_tiles_kernel(const float* __rest
     if (mloc >= ntiles) return;
     const int b = mloc % tiles_x, a = (mloc / tiles_x) % tiles_y, n = mloc / (tiles_x * tiles_y);
     const int oy = V * a + org, ox = V * b + org;
-    for (int idx = tid; idx < T * T * (CG / 4); idx += 256) {
-        const int q = idx & 1, px = idx >> 1, y = px >> 5, x = px & 31;
-        const int gy = oy + y, gx = ox + x;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (y < valid && x < valid && gy >= 0 && gy < H && gx >= 0 && gx < W && c0 + 4 * q < cs)
-            v = *(const f32x4*)(in + (((size_t)n * H + gy) * W + gx) * cs + c0 + 4 * q);
+    // ALL eight loads of a thread first, branch-free (an address inside the tensor for the slots that are padding, the value zeroed
+    // afterwards): written as `if (inside) v = load` in a rolled loop, hipcc issued one load, waited for it (vmcnt(0)) and wrote it to
+    // LDS before the next - eight (here) / seventeen (inverse transform) HBM latencies in series per workgroup, which is what these
+    // kernels spent their time on (round 3: 128 -> 75 us and 198 -> 115 us per launch)
+    {
+        constexpr int NLD = T * T * (CG / 4) / 256;
+        static_assert(NLD * 256 == T * T * (CG / 4), "whole load rounds");
+        f32x4 v[NLD];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) R[(4 * q + j) * RP + y * RS + x] = v[j];
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + 256 * i, q = idx & 1, px = idx >> 1, y = px >> 5, x = px & 31;
+            const int gy = oy + y, gx = ox + x;
+            const bool ok = y < valid && x < valid && gy >= 0 && gy < H && gx >= 0 && gx < W && c0 + 4 * q < cs;
+            const size_t off = ok ? (((size_t)n * H + gy) * W + gx) * cs + c0 + 4 * q : 0;
+            v[i] = *(const f32x4*)(in + off);
+            if (!ok) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + 256 * i, q = idx & 1, px = idx >> 1, y = px >> 5, x = px & 31;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) R[(4 * q + j) * RP + y * RS + x] = v[i][j];
+        }
     }
     __syncthreads();
     {   // rows: one real row of 32 per thread
@@ -148,9 +163,21 @@ __global__ __launch_bounds__(256) void spec_ifft_out_kernel(const float2* __rest
     if (mloc >= ntiles) return;
     const int b = mloc % tiles_x, a = (mloc / tiles_x) % tiles_y, n = mloc / (tiles_x * tiles_y);
     const size_t m = (size_t)m0 + mloc;
-    for (int idx = tid; idx < NF * CG; idx += 256) {
-        const int c = idx & (CG - 1), f = idx >> 3;
-        Cx[c * PS + f] = (c0 + c < Np) ? Yf[(m * NF + f) * Np + c0 + c] : make_float2(0.f, 0.f);
+    {   // all 17 loads of a thread first (see spec_fft_tiles_kernel)
+        constexpr int NLD = NF * CG / 256;
+        static_assert(NLD * 256 == NF * CG, "whole load rounds");
+        float2 v[NLD];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + 256 * i, c = idx & (CG - 1), f = idx >> 3;
+            v[i] = Yf[(m * NF + f) * Np + min(c0 + c, Np - 1)];
+            if (c0 + c >= Np) v[i] = make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + 256 * i, c = idx & (CG - 1), f = idx >> 3;
+            Cx[c * PS + f] = v[i];
+        }
     }
     __syncthreads();
     if (tid < CG * KX) {
@@ -178,16 +205,30 @@ __global__ __launch_bounds__(256) void spec_ifft_out_kernel(const float2* __rest
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < V * V * (CG / 4); idx += 256) {
-        const int q = idx & 1, px = idx >> 1, y = px / V, x = px - y * V;
-        const int gy = V * a + y, gx = V * b + x, c = c0 + 4 * q;
-        if (gy >= H || gx >= W || c >= cs) continue;
-        float* o = out + (((size_t)n * H + gy) * W + gx) * cs + c;
-        f32x4 v;
+    {
+        constexpr int NST = (V * V * (CG / 4) + 255) / 256;            // 5 rounds (4.5 used)
+        f32x4 old[NST];
+        if (accumulate) {                           // the read-modify-write of the data gradient: all reads in flight before the first add
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (c + j < Cout) ? R[(4 * q + j) * RP + y * RS + x] + (bias ? bias[c + j] : 0.f) : 0.f;
-        if (accumulate) { const f32x4 old = *(const f32x4*)o; v += old; }
-        *(f32x4*)o = v;
+            for (int i = 0; i < NST; ++i) {
+                const int idx = tid + 256 * i, q = idx & 1, px = idx >> 1, y = px / V, x = px - y * V;
+                const int gy = V * a + y, gx = V * b + x, c = c0 + 4 * q;
+                const bool ok = idx < V * V * (CG / 4) && gy < H && gx < W && c < cs;
+                old[i] = *(const f32x4*)(out + (ok ? (((size_t)n * H + gy) * W + gx) * cs + c : 0));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int idx = tid + 256 * i, q = idx & 1, px = idx >> 1, y = px / V, x = px - y * V;
+            const int gy = V * a + y, gx = V * b + x, c = c0 + 4 * q;
+            if (idx >= V * V * (CG / 4) || gy >= H || gx >= W || c >= cs) continue;
+            float* o = out + (((size_t)n * H + gy) * W + gx) * cs + c;
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (c + j < Cout) ? R[(4 * q + j) * RP + y * RS + x] + (bias ? bias[c + j] : 0.f) : 0.f;
+            if (accumulate) v += old[i];
+            *(f32x4*)o = v;
+        }
     }
 }
 
