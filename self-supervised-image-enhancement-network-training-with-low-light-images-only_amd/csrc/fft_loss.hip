@@ -348,11 +348,14 @@ __global__ __launch_bounds__(FFT_COLS_THREADS) void fft_cols_kernel(const FftPar
     fill_twiddles<NT>(tw, H, pow2 ? (H >> 1) : H, tid);
     float2* wsx = (float2*)p.ws + (size_t)pl * 2 * g.WH * H;
     float2* wss = wsx + (size_t)g.WH * H;
+    // (branch-free bodies in the three global-memory loops of this kernel: with `if (inside) v = load` hipcc waits for every
+    // predicated load before it issues the next one - vmcnt(0) per iteration - and a workgroup pays its HBM / L2 latencies in series)
 #pragma unroll 4
     for (int id = tid; id < CB * H; id += NT) {
         const int h = id >> g.logCB, col = id & (CB - 1), kx = kx0 + col;      // lanes along the CB columns: one 128-byte run per row
-        float2 va = make_float2(0.f, 0.f), vb = va;
-        if (kx < g.WH) { va = wsx[(size_t)h * g.WH + kx]; vb = wss[(size_t)h * g.WH + kx]; }
+        const size_t o = (size_t)h * g.WH + min(kx, g.WH - 1);
+        float2 va = wsx[o], vb = wss[o];
+        if (kx >= g.WH) { va = make_float2(0.f, 0.f); vb = va; }
         a[col * LS + h] = va; b[col * LS + h] = vb;
     }
     __syncthreads();
@@ -360,21 +363,19 @@ __global__ __launch_bounds__(FFT_COLS_THREADS) void fft_cols_kernel(const FftPar
     if (pow2) fft_pass<false, NT>(a, tw, p.logH, H, p.logH, 2 * CB, g.logCB + 1, 1, LS, tid);      // a and b are adjacent: 2 CB lines in one go
     else { dft_lines<false, NT>(a, a2, tw, H, CB, 1, LS, tid); dft_lines<false, NT>(b, b2, tw, H, CB, 1, LS, tid); fa = a2; fb = b2; }
     float lsum = 0.f;
+#pragma unroll 4
     for (int id = tid; id < CB * H; id += NT) {
-        const int col = id / H, ky = id - col * H, kx = kx0 + col;
+        const int col = id / H, ky = id - col * H, kx = kx0 + col, kxc = min(kx, g.WH - 1);
         const int pos = col * LS + (pow2 ? brev_n(ky, p.logH) : ky);
-        float2 G = make_float2(0.f, 0.f);
-        if (kx < g.WH) {
-            const float2 Fx = fa[pos], Fs = fb[pos];
-            const float ax = sqrtf(Fx.x * Fx.x + Fx.y * Fx.y), as = sqrtf(Fs.x * Fs.x + Fs.y * Fs.y);
-            const float diff = ax - as;
-            float wgt = p.mask[ky * W + kx] ? 1.f : 0.f;
-            if (kx != 0 && 2 * kx != W) wgt += p.mask[(ky ? H - ky : 0) * W + (W - kx)] ? 1.f : 0.f;     // mirror bin in the dropped half
-            lsum += wgt * fabsf(diff);
-            const float coef = as > 0.f ? -((float)(diff > 0.f) - (float)(diff < 0.f)) * p.scale_g * wgt / as : 0.f;
-            G = make_float2(coef * Fs.x, coef * Fs.y);
-        }
-        fb[pos] = G;
+        const bool mir = kxc != 0 && 2 * kxc != W;                              // the mirror bin lives in the dropped half
+        const unsigned char m1 = p.mask[ky * W + kxc], m2 = p.mask[mir ? (ky ? H - ky : 0) * W + (W - kxc) : ky * W + kxc];
+        const float2 Fx = fa[pos], Fs = fb[pos];
+        const float ax = sqrtf(Fx.x * Fx.x + Fx.y * Fx.y), as = sqrtf(Fs.x * Fs.x + Fs.y * Fs.y);
+        const float diff = ax - as;
+        const float wgt = kx < g.WH ? (m1 ? 1.f : 0.f) + (mir && m2 ? 1.f : 0.f) : 0.f;
+        lsum += wgt * fabsf(diff);
+        const float coef = as > 0.f ? -((float)(diff > 0.f) - (float)(diff < 0.f)) * p.scale_g * wgt / as : 0.f;
+        fb[pos] = make_float2(coef * Fs.x, coef * Fs.y);
     }
     __syncthreads();
     const float2* go = fb;
@@ -438,24 +439,35 @@ __global__ __launch_bounds__(FFT_ROWS_THREADS) void fft_rows_inv_grouped_kernel(
     float2* tw = z + BG * R * LS;
     fill_twiddles<NT>(tw, W, W >> 1, tid);
     const size_t pf = (size_t)2 * g.WH * H;
+#pragma unroll 4
     for (int id = tid; id < BG * R * W; id += NT) {
         const int line = id >> p.logW, kx = id & (W - 1), b = line >> g.logR, r = line & (R - 1), h = h0 + r;
-        float2 v = make_float2(0.f, 0.f);
-        if (kx < g.WH && h < H && c0 + b < p.B)
-            v = ((const float2*)p.ws + ((size_t)pn * p.B + c0 + b) * pf + (size_t)g.WH * H)[(size_t)h * g.WH + kx];
+        const bool ok = kx < g.WH && h < H && c0 + b < p.B;
+        float2 v = ((const float2*)p.ws + ((size_t)pn * p.B + min(c0 + b, p.B - 1)) * pf + (size_t)g.WH * H)[(size_t)min(h, H - 1) * g.WH + min(kx, g.WH - 1)];
+        if (!ok) v = make_float2(0.f, 0.f);
         z[line * LS + brev_n(kx, p.logW)] = v;
     }
     __syncthreads();
     fft_pass<true, NT>(z, tw, p.logW, W, p.logW, BG * R, g.logBG + g.logR, 1, LS, tid);
     const size_t base = (size_t)n * H * W;
-    for (int id = tid; id < R * W * Q; id += NT) {
-        const int q = id % Q, px = id / Q, r = px >> p.logW, w = px & (W - 1), h = h0 + r, c = c0 + 4 * q;
-        if (h >= H || c >= p.s_cs || c >= p.B) continue;
-        float* gp = p.gS + (base + (size_t)h * W + w) * p.s_cs + c;
-        f32x4 gv = *(const f32x4*)gp;
+    // read-modify-write of gS, four elements per thread at a time with all four reads in flight before the first add (a rolled
+    // load -> add -> store loop pays one HBM latency per iteration)
+    for (int id0 = tid; id0 < R * W * Q; id0 += 4 * NT) {
+        f32x4 gv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (c + j < p.B) gv[j] += z[((4 * q + j) * R + r) * LS + w].x;
-        *(f32x4*)gp = gv;
+        for (int u = 0; u < 4; ++u) {
+            const int id = id0 + u * NT, q = id % Q, px = id / Q, r = px >> p.logW, w = px & (W - 1), h = h0 + r, c = c0 + 4 * q;
+            const bool ok = id < R * W * Q && h < H && c < p.s_cs && c < p.B;
+            gv[u] = *(const f32x4*)(p.gS + (ok ? (base + (size_t)h * W + w) * p.s_cs + c : 0));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int id = id0 + u * NT, q = id % Q, px = id / Q, r = px >> p.logW, w = px & (W - 1), h = h0 + r, c = c0 + 4 * q;
+            if (id >= R * W * Q || h >= H || c >= p.s_cs || c >= p.B) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (c + j < p.B) gv[u][j] += z[((4 * q + j) * R + r) * LS + w].x;
+            *(f32x4*)(p.gS + (base + (size_t)h * W + w) * p.s_cs + c) = gv[u];
+        }
     }
 }
 
