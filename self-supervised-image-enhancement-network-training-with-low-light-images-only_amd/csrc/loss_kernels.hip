@@ -753,6 +753,29 @@ __global__ void mask_axpy_kernel(const float* __restrict__ src, int src_cs, cons
     }
 }
 
+// the same on float4 (channel counts and strides that are multiples of 4, 16-byte aligned tensors): a quarter of the vector-memory
+// instructions, and a thread's two or three loads are independent (the scalar kernel above moves 4 bytes per lane and instruction)
+__global__ void mask_axpy_vec_kernel(const float* __restrict__ src, int src_cs, const float* __restrict__ y, int y_cs, int mode,
+                                     float* __restrict__ dst, int dst_cs, long npix, int C4, int accumulate)
+{
+    const long total = npix * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / C4; const int c = (int)(i % C4) * 4;
+        f32x4 v = *(const f32x4*)(src + pix * src_cs + c);
+        f32x4 yy = {1.f, 1.f, 1.f, 1.f}, d = {0.f, 0.f, 0.f, 0.f};
+        if (mode != MASK_NONE) yy = *(const f32x4*)(y + pix * y_cs + c);
+        if (accumulate) d = *(const f32x4*)(dst + pix * dst_cs + c);
+        if (mode == MASK_RELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = yy[j] > 0.f ? v[j] : 0.f;
+        } else if (mode == MASK_SIGMOID) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= yy[j] * (1.f - yy[j]);
+        }
+        *(f32x4*)(dst + pix * dst_cs + c) = accumulate ? d + v : v;
+    }
+}
+
 // adjoint of nearest up-sampling (F.interpolate backward): dst[lo] (+)= sum of src[hi] with src_index(hi) == lo
 __global__ void upsample_adjoint_kernel(const float* __restrict__ src, int Hv, int Wv, int src_cs,
                                         float* __restrict__ dst, int Hs, int Ws, int dst_cs, int N, int C,
@@ -914,6 +937,10 @@ int ssie_launch_ingest(const float* x, long sn, long sc, long sh, long sw, float
 int ssie_launch_mask_axpy(const float* src, int src_cs, const float* y, int y_cs, int mode, float* dst, int dst_cs,
                           long npix, int C, int accumulate, hipStream_t st)
 {
+    if (C % 4 == 0 && src_cs % 4 == 0 && y_cs % 4 == 0 && dst_cs % 4 == 0 && (((uintptr_t)src | (uintptr_t)y | (uintptr_t)dst) & 15) == 0) {
+        hipLaunchKernelGGL(mask_axpy_vec_kernel, dim3(grid_for(npix * (C / 4), 256)), dim3(256), 0, st, src, src_cs, y, y_cs, mode, dst, dst_cs, npix, C / 4, accumulate);
+        return hipGetLastError() == hipSuccess ? 0 : 46;
+    }
     hipLaunchKernelGGL(mask_axpy_kernel, dim3(grid_for(npix * C, 256)), dim3(256), 0, st, src, src_cs, y, y_cs, mode, dst, dst_cs, npix, C, accumulate);
     return hipGetLastError() == hipSuccess ? 0 : 46;
 }

@@ -219,19 +219,32 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
     f32x4 wr[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) wr[t] = *(const f32x4*)(ws + t * 64 + sub * 4);
-    for (int it = slot; it < ((R3 * R3 + 15) & ~15); it += 16) {
-        float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const int yy = y0 - 1 + it / R3, xx = x0 - 1 + it % R3;
-        if (it < R3 * R3 && yy >= 0 && yy < H && xx >= 0 && xx < W) {
-            const f32x4 v = *(const f32x4*)(f + (((size_t)n * H + yy) * W + xx) * 64 + sub * 4);
+    // 21 halo pixels per 16-lane slot, in three batches of seven whose loads all go out before the first dot product (one load ->
+    // nine dots -> shuffles per iteration exposed 21 HBM latencies in series per workgroup: 93 us for a 27-us pass over f)
+    constexpr int NIT = ((R3 * R3 + 15) & ~15) / 16, NB = 7;
+    static_assert(NIT % NB == 0, "whole batches");
+    for (int i0 = 0; i0 < NIT; i0 += NB) {
+        f32x4 v[NB];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc[t] = v[0] * wr[t][0] + v[1] * wr[t][1] + v[2] * wr[t][2] + v[3] * wr[t][3];
+        for (int u = 0; u < NB; ++u) {
+            const int it = slot + 16 * (i0 + u);
+            const int yy = y0 - 1 + it / R3, xx = x0 - 1 + it % R3;
+            const bool ok = it < R3 * R3 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            v[u] = *(const f32x4*)(f + (ok ? (((size_t)n * H + yy) * W + xx) * 64 : 0) + sub * 4);
+            if (!ok) v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-        for (int t = 0; t < 9; ++t) { float a = acc[t]; a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); a += __shfl_xor(a, 8); acc[t] = a; }
-        if (it < R3 * R3) {
+        for (int u = 0; u < NB; ++u) {
+            const int it = slot + 16 * (i0 + u);
+            float acc[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) if (sub == t) T[it * 9 + t] = acc[t];
+            for (int t = 0; t < 9; ++t) acc[t] = v[u][0] * wr[t][0] + v[u][1] * wr[t][1] + v[u][2] * wr[t][2] + v[u][3] * wr[t][3];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) { float a = acc[t]; a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); a += __shfl_xor(a, 8); acc[t] = a; }
+            if (it < R3 * R3) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) if (sub == t) T[it * 9 + t] = acc[t];
+            }
         }
     }
     __syncthreads();
@@ -261,14 +274,18 @@ __global__ __launch_bounds__(256) void skinny_dgrad_kernel(const float* __restri
     for (long pix = (long)blockIdx.x * 16 + (threadIdx.x >> 4); pix < npix; pix += (long)gridDim.x * 16) {
         const int x = (int)(pix % W), y = (int)((pix / W) % H);
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        float g9[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
+        for (int t = 0; t < 9; ++t) {                  // nine unconditional loads (clamped address, value zeroed): no load -> wait chain
             const int py = y - (t / 3 - 1), px = x - (t % 3 - 1);              // output position p with p + tap = q
-            if (py < 0 || py >= H || px < 0 || px >= W) continue;
-            const float g = gD[(pix + (long)(py - y) * W + (px - x)) * d_cs];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] += g * wr[t][j];
+            const bool ok = py >= 0 && py < H && px >= 0 && px < W;
+            g9[t] = gD[(ok ? pix + (long)(py - y) * W + (px - x) : pix) * d_cs];
+            if (!ok) g9[t] = 0.f;
         }
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] += g9[t] * wr[t][j];
         *(f32x4*)(Gf + pix * 64 + sub * 4) = a;
     }
 }
@@ -290,14 +307,17 @@ __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const float* __restri
     for (long pix = (long)blockIdx.x * 16 + slot; pix < npix; pix += (long)gridDim.x * 16) {
         const int x = (int)(pix % W), y = (int)((pix / W) % H);
         const f32x4 v = *(const f32x4*)(f + pix * 64 + sub * 4);
+        float g9[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
+        for (int t = 0; t < 9; ++t) {                  // unconditional loads (see skinny_dgrad_kernel)
             const int py = y - (t / 3 - 1), px = x - (t % 3 - 1);
-            if (py < 0 || py >= H || px < 0 || px >= W) continue;
-            const float g = gD[(pix + (long)(py - y) * W + (px - x)) * d_cs];
-            acc[t] += v * g;
-            if (t == 4 && sub == 0) accb += g;
+            const bool ok = py >= 0 && py < H && px >= 0 && px < W;
+            g9[t] = gD[(ok ? pix + (long)(py - y) * W + (px - x) : pix) * d_cs];
+            if (!ok) g9[t] = 0.f;
         }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] += v * g9[t];
+        if (sub == 0) accb += g9[4];
     }
 #pragma unroll
     for (int t = 0; t < 9; ++t)
