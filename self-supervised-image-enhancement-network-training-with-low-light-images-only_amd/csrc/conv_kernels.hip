@@ -701,7 +701,9 @@ __device__ __forceinline__ void ssie_pack_one(const PackDesc& d, long idx4)
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int k = kb8 + 2 * s2 + e;
-                f2[e] = (k < d.K && n < d.N) ? d.w[(long)n * d.s_n + (long)k * d.s_k + ts] : 0.f;
+                // (unconditional load from a clamped index, value zeroed afterwards: predicated loads are waited for one by one)
+                const float wv = d.w[(long)min(n, d.N - 1) * d.s_n + (long)min(k, d.K - 1) * d.s_k + ts];
+                f2[e] = (k < d.K && n < d.N) ? wv : 0.f;
             }
             w[s2] = ssie_pack2bf(f2[0], f2[1]);
         }
@@ -714,7 +716,8 @@ __device__ __forceinline__ void ssie_pack_one(const PackDesc& d, long idx4)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         int k = kb + s;
-        v[s] = (k < d.K && n < d.N) ? d.w[(long)n * d.s_n + (long)k * d.s_k + ts] : 0.f;
+        const float wv = d.w[(long)min(n, d.N - 1) * d.s_n + (long)min(k, d.K - 1) * d.s_k + ts];
+        v[s] = (k < d.K && n < d.N) ? wv : 0.f;
     }
     ((f32x4*)d.dst)[idx4] = v;
 }
@@ -735,7 +738,8 @@ __device__ __forceinline__ void ssie_pack_wino_one(const PackDesc& d, long idx)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int k = kb + s;
-            g[t][s] = (k < d.K && n < d.N) ? d.w[(long)n * d.s_n + (long)k * d.s_k + ts] : 0.f;
+            const float wv = d.w[(long)min(n, d.N - 1) * d.s_n + (long)min(k, d.K - 1) * d.s_k + ts];      // 36 loads in flight together
+            g[t][s] = (k < d.K && n < d.N) ? wv : 0.f;
         }
     }
     f32x4 m[12];      // G g: 4 x 3

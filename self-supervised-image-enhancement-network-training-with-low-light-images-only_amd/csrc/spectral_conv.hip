@@ -607,10 +607,11 @@ __global__ __launch_bounds__(256) void spec_bias_partial_kernel(const float2* __
     const int co = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int m0 = blockIdx.x * 64;
     float s = 0.f;
-#pragma unroll 4
+#pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int m = m0 + part + 4 * i;
-        if (m < M) s += Gn[(size_t)m * NF * 64 + co].x;
+        const float v = Gn[(size_t)min(m, M - 1) * NF * 64 + co].x;        // (unconditional: predicated loads are waited for one by one)
+        s += m < M ? v : 0.f;
     }
     red[part][co] = s;
     __syncthreads();
