@@ -24,6 +24,11 @@ int ssie_plan_profile_list(void* plan, const float* x, const long* strides4, voi
 /* launches per op list: {enhance forward, second decomposition pass, loss + backward} */
 int ssie_plan_num_ops(void* plan, int* counts3);
 
+/* the bf16 attention of the enhance-only path on its own: qkv fp32 (N, T, 192) -> out bf16 (N, T, 64); scratch (optional, from
+ * ..._scratch_bytes) enables the pre-converted key / value path the plan uses from 256 tokens on */
+size_t ssie_debug_attention_bf16_scratch_bytes(int N, int T);
+int ssie_debug_attention_fwd_bf16(const float* qkv, void* out_bf16, int N, int T, void* scratch, size_t scratch_bytes, void* stream);
+
 /* launch heuristics */
 void ssie_debug_set_overlap(int on);                    /* [0] 1 = slab reductions of the weight gradients on a side stream; 0 = launch order on the caller's stream */
 void ssie_debug_set_graph(int on);                      /* [0] 1 = ssie_plan_loss_fwd_bwd (with backward) replays one hipGraph per plan behind the ingest */
@@ -51,15 +56,15 @@ void ssie_debug_set_fft_grouped(int v);                 /* [1] 0 = Fourier loss 
 void ssie_debug_set_loss_chunk_lpp(int v);              /* [8] lanes per pixel of loss_chunk_kernel: 8 = 32-band chunks on 8x16 tiles, 16 = 64-band chunks on 4x16 tiles */
 void ssie_debug_set_loss_chunked(int v);                /* [0] 1 = the band-chunked tiled loss kernel (loss_chunk_kernel, normally only above 252 bands) for every band count */
 void ssie_debug_set_wino(int v);                        /* [1] 0 = stride-1 3x3 launches never run the Winograd F(2x2,3x3) kernel (plans created afterwards) */
-void ssie_debug_set_wino_min_tiles(int v);
+void ssie_debug_set_wino_min_tiles(int v);               /* [256] fewest 16x32x32-channel tiles for which it is chosen */
 void ssie_debug_set_wgrad_wino(int v);                  /* [1] 0 = stride-1 3x3 weight gradients never run the Winograd F(3x3,2x2) kernel (plans created afterwards) */
-void ssie_debug_set_wgrad_wino_min_tiles(int v);        /* [32] fewest 8x16 position tiles for which it is chosen */              /* [256] fewest 16x32x32-channel tiles for which it is chosen */
+void ssie_debug_set_wgrad_wino_min_tiles(int v);        /* [256] fewest 8x16 position tiles for which it is chosen */
 void ssie_debug_set_fused_tail(int on);                 /* [1] 0 = inference keeps feature_fusion / final_conv / compose as separate launches (plans bound afterwards) */
 void ssie_debug_set_spectral9(int on);                  /* [1] 0 = the 9 x 9 convolution (shallow_conv) on the direct MFMA kernels instead of the frequency domain (plans created afterwards) */
 void ssie_debug_set_skinny_final(int on);               /* [1] 0 = final_conv (64 -> 1) forward / gradients on the MFMA tile kernels (plans created afterwards) */
 void ssie_debug_set_loss_generic(int v);                 /* [0] 1 = the half-wave-per-pixel loss kernel instead of the tiled one */
-void ssie_debug_set_wgrad_sliding(int v);
-void ssie_debug_set_wgrad_rows2(int v);                 /* [1] 0 = one 9x9 kernel row per workgroup (gradient tile re-read 9x instead of 5x) */               /* [1] 0 = generic wgrad K loop everywhere */
+void ssie_debug_set_wgrad_sliding(int v);               /* [1] 0 = generic wgrad K loop everywhere */
+void ssie_debug_set_wgrad_rows2(int v);                 /* [1] 0 = one 9x9 kernel row per workgroup (gradient tile re-read 9x instead of 5x) */
 /* (diagnostic builds compiled with -DSSIE_STAMP additionally export two s_memtime stamp-buffer setters, see tools/stamp_*.py;
  * the shipped library has no stamp code) */
 

@@ -376,7 +376,9 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16p_kernel(const float* __rest
                 // slow path (whole wave): both lane halves of a query share the reference
                 mb = fmaxf(mb, __shfl_xor(mb, 32));
                 const float d = first ? mb : fmaxf(mb, 0.f);        // afterwards the reference only ever rises
-                const float alpha = __builtin_amdgcn_exp2f(-d);
+                // the first block only moves the reference (lsum and oacc are still 0): no rescale - exp2(-d) is +inf when every logit
+                // of the first 32 keys sits below -128, and 0 * inf would leave that query NaN for good
+                const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-d);
                 lsum *= alpha;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) oacc[r] *= alpha;
@@ -615,6 +617,14 @@ int ssie_launch_attn_bwd(const float* qkv, int qs, const float* o, const float* 
 }
 
 // ---- granular C-ABI (parity tests) ----
+// TEST ENTRY (include/ssie_debug.h): the bf16 attention of the enhance-only path on its own; out = bf16 (N, T, 64)
+extern "C" size_t ssie_debug_attention_bf16_scratch_bytes(int N, int T) { return ssie_attn_bf16_scratch_bytes(N, T); }
+extern "C" int ssie_debug_attention_fwd_bf16(const float* qkv, void* out_bf16, int N, int T, void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (!qkv || !out_bf16 || N < 1 || T < 1) return 1;
+    return ssie_launch_attn_fwd_bf16(qkv, 192, out_bf16, 64, N, T, (hipStream_t)stream, scratch, scratch_bytes) ? 4 : 0;
+}
+
 extern "C" int ssie_attention_fwd(const float* qkv, float* out, float* lse, int N, int T, void* stream)
 {
     if (!qkv || !out || !lse || N < 1 || T < 1) return 1;

@@ -125,8 +125,10 @@ __device__ __forceinline__ void ssie_epilogue_ht(const ConvParams& p, const floa
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[g][j] = __frcp_rn(1.f + __expf(-v[g][j]));
     }
+    // the second output may have its own pixel stride (one launch per image: the R|I tensor and its bf16 twin)
+    const size_t opix2 = (p.out2 && p.out2_cstride) ? (size_t)((unsigned)(opix - p.out_coff) / (unsigned)p.out_cstride) * p.out2_cstride + p.out_coff : opix;
     if (p.out2) {
-        unsigned short* o2 = (unsigned short*)p.out2 + opix + c0;
+        unsigned short* o2 = (unsigned short*)p.out2 + opix2 + c0;
 #pragma unroll
         for (int g = 0; g < 4; ++g) if (SSIE_X_KEEP(full[g], v[g][0])) *(uint2*)(o2 + 8 * g) = ssie_pack4bf(v[g]);
     }
@@ -170,7 +172,7 @@ __device__ __forceinline__ void ssie_epilogue_ht(const ConvParams& p, const floa
             float t = acc[4 * g + j] + bias_s[c + j];
             if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
             else if (p.act == ACT_SIGMOID) t = 1.f / (1.f + expf(-t));
-            if (p.out2) ((unsigned short*)p.out2)[o] = ssie_f2bf(t);
+            if (p.out2) ((unsigned short*)p.out2)[opix2 + c + j] = ssie_f2bf(t);
             if (p.addsrc) t += ssie_bf2f(((const unsigned short*)p.addsrc)[o]);
             if (p.out_bf16) ((unsigned short*)p.out)[o] = ssie_f2bf(t); else p.out[o] = t;
         }

@@ -613,6 +613,9 @@ int ssie_launch_fft_loss(const FftParams& p, hipStream_t st)
 {
     const int kind = p.path;                           // decided by ssie_fft_set_logs (the workspace and partial-sum sizes follow it)
     if (!kind || !ssie_fft_supported(p.H, p.W)) return 51;
+    // the geometry below is recomputed from the CURRENT development switches: it must still fit the allocation
+    if (ssie_fft_path(p.N, p.B, p.H, p.W) != kind || ssie_fft_workspace_floats(p.N, p.B, p.H, p.W) > p.ws_floats ||
+        ssie_fft_partials(p.N, p.B, p.H, p.W) > p.npartials) return 56;
     if (kind == 3) return launch_fft_big(p, st);
     if ((kind == 1) != (p.logH >= 0)) return 51;
     const int M = p.H > p.W ? p.H : p.W;

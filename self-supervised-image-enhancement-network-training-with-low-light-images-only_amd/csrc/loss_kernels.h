@@ -30,6 +30,9 @@ struct FftParams {
     float* partials;                 // [ssie_fft_partials(N, B, H, W)]
     float* ws;                       // three-pass path only: ssie_fft_workspace_floats(N, B, H, W) floats
     int path;                        // ssie_fft_path(N, B, H, W) at the time ssie_fft_set_logs ran: 1 / 2 whole plane in LDS, 3 three passes
+    // capacities of `ws` / `partials` as ALLOCATED: the launch geometry follows process-global development switches (chunk size,
+    // grouped rows), so a launch whose geometry no longer fits what was allocated under earlier settings is refused, not run
+    size_t ws_floats; int npartials;
 };
 
 int ssie_launch_loss_direct(const LossParams& p, int nblk, hipStream_t st);

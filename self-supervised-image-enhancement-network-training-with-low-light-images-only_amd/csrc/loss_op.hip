@@ -68,6 +68,7 @@ extern "C" int ssie_selfsup_loss_fwd_bwd(const float* x, int x_cs, const float* 
     fp.N = N; fp.B = bands; fp.H = H; fp.W = W;
     ssie_fft_set_logs(fp);
     fp.scale_g = (float)(coefs8[4] / (n * c * h * wd)); fp.inv_n0 = lp.inv_n0; fp.partials = w + l.fpart; fp.ws = w + l.fftws;
+    fp.ws_floats = l.total - l.fftws; fp.npartials = (int)(l.cf - l.fpart);
     if (ssie_launch_fft_loss(fp, st)) return SSIE_E_LAUNCH;
     const float cf[6] = {coefs8[0], coefs8[1], coefs8[2], coefs8[3], coefs8[4], coefs8[5]};
     if (ssie_launch_loss_finalize(w + l.lpart, kLossBlocks, w + l.fpart, ssie_fft_partials(N, bands, H, W), cf, scalars7, st)) return SSIE_E_LAUNCH;

@@ -59,7 +59,7 @@ struct Plan {
     bool spectral = false; int sp_Mt = 0, sp_Kp = 0, sp_slices = 2;      // 544 frequencies x 2 slices = 1 088 reduction workgroups
     size_t sp_Xf = 0, sp_Yf = 0, sp_Zf = 0, sp_Gn = 0, sp_Bf = 0, sp_Bd = 0, sp_dW = 0;
     int counter_cursor = 0;
-    int loss_blocks = 0, fft_blocks = 0;
+    int loss_blocks = 0, fft_blocks = 0; size_t fftws_floats = 0;
     float coefs[8];
     // bound state
     float* ws = nullptr; float* P = nullptr; float* G = nullptr;
@@ -185,7 +185,8 @@ void build_buffers(Plan& pl)
     pl.lpart_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + (size_t)pl.loss_blocks * 8, 64);
     pl.fpart_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + (size_t)pl.fft_blocks, 64);
     pl.scal_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 16, 64);
-    pl.fftws_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + ssie_fft_workspace_floats(N, B, H, W), 64);   // three-pass Fourier loss (band-grouped rows, or planes larger than the LDS)
+    pl.fftws_floats = ssie_fft_workspace_floats(N, B, H, W);
+    pl.fftws_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + pl.fftws_floats, 64);   // three-pass Fourier loss (band-grouped rows, or planes larger than the LDS)
     pl.mask_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + ((size_t)H * W + 3) / 4, 64);
     pl.tailw_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 3 * 9 * 64 + 16, 64);     // composite weights of the fused tail
     {   // spectral 9 x 9 (tile-major): X^ of both passes [2 Mt][f][Kp], Y^ / halo-G^ [Mt][f][64], Z^ [Mt][f][Kp], no-halo G^ [2 Mt][f][64], weights, dW^ slices
@@ -280,6 +281,7 @@ struct Builder {
             int rc = ssie_make_conv_bf16(p, srcs.data(), (int)srcs.size(), pl.N, Hv, Wv, t, stride, Ho, Wo, wp, L.cout,
                                          pl.buf(out), !f32o, ob.H, ob.W, f32o ? ob.cs : ssie_round_up(ob.cs, 8), out_coff, 1, 0, 0, e);
             if (rc) return rc;
+            if (e.out2) p.out2_cstride = pl.bi("RLh").cs * 2;      // the twin's own pixel stride (B + 1 padded to 8 bf16 elements)
             push(ops, p, L.cin);
             return 0;
         }
@@ -448,9 +450,12 @@ struct Builder {
         ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_spec_ifft(Zf, 0, Mt, Kp, N, H, W, xp, xcs, B, nullptr, 1, st); }, K_SPEC, 0.0, "spectral 9x9: ifft dgrad"));
     }
     // weight gradient over both passes: g = pass-1 half of the [Gsh ; Gsh_2] pair, X^ of x and S still in the workspace
-    void spec_wgrad(std::vector<Fn>& ops, const LayerP& L, const char* g)
+    int spec_wgrad(std::vector<Fn>& ops, const LayerP& L, const char* g)
     {
-        if (dry) return;
+        if (dry) return 0;
+        // the bias-gradient launch stages ceil(2 Mt / 64) * 64 partial sums in the shared 256 x 256-float scratch: many small patches
+        // (4 tiles per 25 x 25 patch) can exceed it while still inside the 32-bit tensor guard
+        if (((size_t)2 * pl.sp_Mt + 63) / 64 * 64 > (size_t)256 * 256) return SSIE_E_WORKSPACE;
         const int N = pl.N, H = pl.H, W = pl.W, Mt = pl.sp_Mt, Kp = pl.sp_Kp, B = pl.B, ns = pl.sp_slices;
         float2* Xf = spc(pl.sp_Xf); float2* Gn = spc(pl.sp_Gn); float2* dWs = spc(pl.sp_dW);
         const float* gp = pl.buf(g); const int gcs = pl.bi(g).cs; float* dw = pl.G + L.w;
@@ -460,6 +465,7 @@ struct Builder {
         // the layer's bias gradient from the DC bins of the same spectra (instead of a column-sum pass over the gradient tensor)
         float* part = pl.ws + pl.partial_off; float* db = pl.G + L.b;
         ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_spec_bias(Gn, 2 * Mt, part, db, 1, st); }, K_COLSUM, 0.0, "spectral 9x9: bias gradient (DC bins)"));
+        return 0;
     }
 
     void upadj(std::vector<Fn>& ops, const char* src, int Hv, int Wv, const char* dst, int accumulate)
@@ -625,7 +631,7 @@ int build_decomposition_bwd(Builder& b, std::vector<Fn>& ops, const char* xin, i
     CK(b.dgrad(ops, L2, 2, G2.c_str(), 0, 0, 64, G1.c_str(), c1.c_str(), MASK_RELU, 1));
     if (wg) CK(b.wgrad(ops, L1, 1, b.src("sh_1", 64, H, W), 64, H, W, 0, "G1", 0, true, 2));
     CK(b.dgrad(ops, L1, 1, G1.c_str(), 0, 0, 64, Gsh.c_str(), nullptr, 0, 0));
-    if (wg && pl.spectral) b.spec_wgrad(ops, Ls, "Gsh");       // (incl. the bias gradient)
+    if (wg && pl.spectral) CK(b.spec_wgrad(ops, Ls, "Gsh"));   // (incl. the bias gradient)
     else if (wg) CK(b.wgrad(ops, Ls, 1, b.src("x", pl.CX, H, W), pl.B, H, W, 0, "Gsh", 0, true, 2));
     if (wg) CK(b.wgrad(ops, L0, 1, b.src("x", pl.CX, H, W), pl.B, H, W, 0, "G0", 0, true, 2));
     if (input_grad) {
@@ -719,7 +725,7 @@ int build_all(Plan& pl, bool dry)
 {
     // the op lists are rebuilt (new coefficients, new buffers): a captured step graph holds the old launches
     if (pl.gexec) { hipGraphExecDestroy(pl.gexec); pl.gexec = nullptr; }
-    pl.train_calls = 0;
+    pl.train_calls = 0; pl.graph_failed = false;
     Builder b(pl, dry);
     pl.fwd.clear(); pl.pass2.clear(); pl.lossbwd.clear(); pl.slab_seq = 0;
     CK(build_decomposition_fwd(b, pl.fwd, "x", 1));
@@ -745,7 +751,7 @@ int build_all(Plan& pl, bool dry)
         FftParams fp; memset(&fp, 0, sizeof(fp));
         fp.x = lp.x; fp.x_cs = lp.x_cs; fp.S = lp.S; fp.s_cs = lp.s_cs; fp.gS = lp.gS; fp.mask = (const uint8_t*)(pl.ws + pl.mask_off);
         fp.N = N; fp.B = B; fp.H = H; fp.W = W; ssie_fft_set_logs(fp);
-        fp.ws = pl.ws + pl.fftws_off;
+        fp.ws = pl.ws + pl.fftws_off; fp.ws_floats = pl.fftws_floats; fp.npartials = pl.fft_blocks;
         fp.scale_g = (float)(pl.coefs[4] / (n * c * h * w)); fp.inv_n0 = lp.inv_n0; fp.partials = pl.ws + pl.fpart_off;
         ops.push_back(Fn([fp](hipStream_t st) { return ssie_launch_fft_loss(fp, st); }, K_FFT));
         const float* lpart = pl.ws + pl.lpart_off; const float* fpart = pl.ws + pl.fpart_off; float* scal = pl.ws + pl.scal_off;
@@ -768,7 +774,8 @@ int build_all(Plan& pl, bool dry)
     pl.npacks_train = pl.packs.size();
     pl.fwd16.clear();
     const bool tail_ok = pl.fused_tail && ssie_tail_supported(pl.H, pl.W, pl.H2, pl.W2, pl.H4, pl.W4) != 0;
-    if (pl.CX % 8 == 0 && pl.CRL % 8 == 0) {      // bf16 pixels are read in 16-byte (8-channel) slots; e.g. B = 31, 63, 127
+    {   // any band count (model.py:229-234 takes any): bf16 pixels are read in 16-byte (8-channel) slots, so the bf16 input cube
+        // "xh" and the bf16 twin "RLh" of the R|I output have pixel strides padded to 8 (zero channels), whatever B is
         b.h16 = true;           // (the bf16 copy of the input cube is written by ingest16(): strided fp32 in, NHWC bf16 out, one pass)
         CK(build_decomposition_fwd(b, pl.fwd16, "x", 1));
         CK(build_illum_fwd(b, pl.fwd16, tail_ok));
@@ -882,12 +889,13 @@ extern "C" void* ssie_plan_create(int N, int bands, int H, int W, const float* c
 
 extern "C" void ssie_debug_set_overlap(int on) { g_overlap = on; }
 extern "C" void ssie_debug_set_graph(int on) { g_graph = on; }
-// product API (include/ssie_hip.h): replay this plan's train step as one hipGraph from its third call on
+// product API (include/ssie_hip.h): replay this plan's train step as one hipGraph from its second call on (the first call runs every
+// launcher's one-time hipFuncSetAttribute; capture and the first replay happen at the second)
 extern "C" int ssie_plan_set_graph(void* h, int on)
 {
     Plan* pl = (Plan*)h;
     if (!pl) return SSIE_E_ARG;
-    pl->use_graph = on != 0;
+    pl->use_graph = on != 0; pl->graph_failed = false;
     if (!on && pl->gexec) { hipGraphExecDestroy(pl->gexec); pl->gexec = nullptr; }
     return 0;
 }
@@ -997,7 +1005,7 @@ extern "C" int ssie_plan_enhance_fwd_bf16(void* h, const float* x, const long* s
 {
     Plan* pl = (Plan*)h;
     if (!pl || !pl->bound || !x || !strides4) return SSIE_E_ARG;
-    if (pl->fwd16.empty()) return SSIE_E_SHAPE;      // band count not a multiple of 8 after padding: use the fp32 path
+    if (pl->fwd16.empty()) return SSIE_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     CK(pack_all_bf16(pl, st));
     CK(ingest16(pl, x, strides4, st));
@@ -1033,8 +1041,13 @@ extern "C" int ssie_plan_loss_fwd_bwd(void* h, const float* x, const long* strid
             }
             if (!ok) { pl->graph_failed = true; pl->gexec = nullptr; (void)hipGetLastError(); }
         }
-        if (pl->gexec) { ++pl->train_calls; return hipGraphLaunch(pl->gexec, st) == hipSuccess ? 0 : SSIE_E_LAUNCH; }
-        ++pl->train_calls;
+        if (pl->gexec) {
+            ++pl->train_calls;
+            if (hipGraphLaunch(pl->gexec, st) == hipSuccess) return 0;
+            // a failed replay enqueued nothing: drop the graph for good and run this step's launches eagerly below
+            (void)hipGetLastError();
+            hipGraphExecDestroy(pl->gexec); pl->gexec = nullptr; pl->graph_failed = true;
+        } else ++pl->train_calls;
         CK(pack_all(pl, st));
         CK(run_ops(pl->fwd, st));
         CK(run_ops(pl->pass2, st));

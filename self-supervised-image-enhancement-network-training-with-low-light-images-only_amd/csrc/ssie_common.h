@@ -76,6 +76,8 @@ struct ConvParams {
     int out_bf16;           // bf16 inference kernel only: element type of `out` (addsrc / out2 are always bf16 there)
     int wino;               // 1: geometry and weights (U = G g G^T, 16 transform positions) of conv_wino_kernel (conv_wino.hip)
     int tconv;              // 1: all four output-parity classes of a stride-2 transposed 3 x 3 convolution in one launch (conv_tconv.hip)
+    int out2_cstride;       // bf16 inference kernel only: elements per pixel of `out2` when it differs from out_cstride (0 = the same) -
+                            // the fp32 R|I output (B + 1 padded to 4) and its bf16 twin (padded to 8) at band counts like 64 or 256
 };
 
 struct WgradParams {

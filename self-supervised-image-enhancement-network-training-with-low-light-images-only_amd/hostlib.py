@@ -28,30 +28,59 @@ class SsieError(RuntimeError):
     pass
 
 
+# development switches (include/ssie_debug.h), honoured ONLY when SSIE_DEBUG=1 (tools/ and A/B scripts set it): a product process
+# with stray SSIE_* variables in its environment behaves exactly like one without (tests/test_host_cpu.py)
+_DEBUG_ENV = (("SSIE_OVERLAP", "ssie_debug_set_overlap"), ("SSIE_GRAPH", "ssie_debug_set_graph"), ("SSIE_MIN_TILES16", "ssie_debug_set_fprop_min_tiles16"),
+              ("SSIE_WGRAD_SLIDING", "ssie_debug_set_wgrad_sliding"), ("SSIE_V2_STRIDE2", "ssie_debug_set_fprop_v2_stride2"),
+              ("SSIE_WIDE", "ssie_debug_set_fprop_wide"), ("SSIE_BF16_WS", "ssie_debug_set_bf16_ws"), ("SSIE_BF16_RESW", "ssie_debug_set_bf16_resw"),
+              ("SSIE_BF16_WS_GEO", "ssie_debug_set_bf16_ws_geo"), ("SSIE_BF16_CONV9", "ssie_debug_set_bf16_conv9"),
+              ("SSIE_ATTN_PREPASS", "ssie_debug_set_attn_bf16_prepass"), ("SSIE_FFT_CHUNK_MB", "ssie_debug_set_fft_chunk_mb"),
+              ("SSIE_REDUCE_WIDE_MIN", "ssie_debug_set_wgrad_reduce_wide_min"), ("SSIE_FFT_GROUPED", "ssie_debug_set_fft_grouped"),
+              ("SSIE_LOSS_CHUNKED", "ssie_debug_set_loss_chunked"), ("SSIE_LOSS_CHUNK_LPP", "ssie_debug_set_loss_chunk_lpp"),
+              ("SSIE_LOSS_GENERIC", "ssie_debug_set_loss_generic"), ("SSIE_V2_SPLIT", "ssie_debug_set_fprop_v2_split"))
+
+
+def debug_enabled() -> bool:
+    return os.environ.get("SSIE_DEBUG") == "1"
+
+
+def declared_symbols():
+    """every entry point include/ssie_hip.h declares (the drop-in boundary)"""
+    import re
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "ssie_hip.h")
+    return sorted(set(re.findall(r"\b(ssie_[a-z0-9_]+)\s*\(", open(hdr).read())))
+
+
 def lib():
     """Load libssie_hip.so.  Load-only: building happens in `__graft_entry__.build()` / `python -m ssie_amd.build` BEFORE any
     process touches the GPU (a GPU-initialised process must not spawn compiler children, and N ranks must not race on one
-    output file).  A missing or stale library is a loud error, never a fallback."""
+    output file).  A missing or stale library is a loud error, never a fallback.  With SSIE_DEBUG=1 (development only) a second
+    build can be selected with SSIE_HIP_LIB for A/B runs inside one GPU session and the SSIE_* switches above are applied; either
+    way the library must export the whole boundary and identify itself as a gfx950 build."""
     global _LIB
     if _LIB is not None:
         return _LIB
     path = _build.LIB
-    if os.environ.get("SSIE_HIP_LIB"):       # dev switch for A/B runs of two builds inside one GPU session
+    if debug_enabled() and os.environ.get("SSIE_HIP_LIB"):
         path = os.environ["SSIE_HIP_LIB"]
+        if not os.path.exists(path):
+            raise SsieError(f"SSIE_HIP_LIB={path} does not exist")
     elif not os.path.exists(path):
         raise SsieError(f"{path} is missing: build it first with `python -c 'import __graft_entry__ as g; g.build()'`")
     elif not _build.up_to_date():
         raise SsieError(f"{path} is older than its sources: rebuild with `python -c 'import __graft_entry__ as g; g.build()'`")
     L = C.CDLL(path)
+    missing = [n for n in declared_symbols() if not hasattr(L, n)]
+    if missing:
+        raise SsieError(f"{path} does not export {missing[:4]}{'...' if len(missing) > 4 else ''}: not a build of this source tree")
     L.ssie_version.restype = C.c_char_p
+    if b"gfx950" not in (L.ssie_version() or b""):
+        raise SsieError(f"{path}: ssie_version() = {L.ssie_version()!r}, expected a gfx950 build")
     L.ssie_op_workspace_bytes.restype = C.c_size_t
-    # dev switches (include/ssie_debug.h); unset = the library's defaults
-    for env, fn in (("SSIE_OVERLAP", "ssie_debug_set_overlap"), ("SSIE_GRAPH", "ssie_debug_set_graph"), ("SSIE_MIN_TILES16", "ssie_debug_set_fprop_min_tiles16"),
-                    ("SSIE_WGRAD_SLIDING", "ssie_debug_set_wgrad_sliding"), ("SSIE_V2_STRIDE2", "ssie_debug_set_fprop_v2_stride2"),
-                    ("SSIE_WIDE", "ssie_debug_set_fprop_wide"), ("SSIE_BF16_WS", "ssie_debug_set_bf16_ws"), ("SSIE_BF16_RESW", "ssie_debug_set_bf16_resw"), ("SSIE_BF16_WS_GEO", "ssie_debug_set_bf16_ws_geo"), ("SSIE_BF16_CONV9", "ssie_debug_set_bf16_conv9"), ("SSIE_ATTN_PREPASS", "ssie_debug_set_attn_bf16_prepass"), ("SSIE_FFT_CHUNK_MB", "ssie_debug_set_fft_chunk_mb"), ("SSIE_REDUCE_WIDE_MIN", "ssie_debug_set_wgrad_reduce_wide_min"), ("SSIE_FFT_GROUPED", "ssie_debug_set_fft_grouped"),
-                    ("SSIE_LOSS_CHUNKED", "ssie_debug_set_loss_chunked"), ("SSIE_LOSS_CHUNK_LPP", "ssie_debug_set_loss_chunk_lpp"), ("SSIE_LOSS_GENERIC", "ssie_debug_set_loss_generic"), ("SSIE_V2_SPLIT", "ssie_debug_set_fprop_v2_split")):
-        if os.environ.get(env) is not None:
-            getattr(L, fn)(int(os.environ[env]))
+    if debug_enabled():
+        for env, fn in _DEBUG_ENV:
+            if os.environ.get(env) is not None:
+                getattr(L, fn)(int(os.environ[env]))
     _LIB = L
     return L
 
@@ -300,9 +329,9 @@ class Plan:
               "ssie_plan_enhance_fwd")
 
     def has_bf16(self) -> bool:
-        """the bf16 enhance-only list exists for this band count (padded B and B+1 multiples of 8, e.g. 31, 63, 127)"""
-        b = self.shape[1]
-        return ((b + 3) // 4 * 4) % 8 == 0 and ((b + 4) // 4 * 4) % 8 == 0
+        """the bf16 enhance-only list exists for every band count since round 4 (the bf16 input cube and the bf16 twin of the
+        R|I output carry their own pixel strides, padded to 8 channels); kept so callers need not know that"""
+        return True
 
     def loss_fwd_bwd(self, x, backward=True):
         check(self.L.ssie_plan_loss_fwd_bwd(self.h, x.data_ptr(), self._strides(x), int(backward),
@@ -363,6 +392,19 @@ def attention_fwd(qkv: torch.Tensor):
     out = torch.empty(n, t, 64, device=qkv.device); lse = torch.empty(n, 4, t, device=qkv.device)
     check(lib().ssie_attention_fwd(ptr(qkv), ptr(out), ptr(lse), n, t, stream_ptr()), "ssie_attention_fwd")
     return out, lse
+
+
+def attention_fwd_bf16(qkv: torch.Tensor, prepass: bool = True):
+    """TEST ENTRY (include/ssie_debug.h): the enhance-only path's bf16 attention.  qkv fp32 (N, T, 192) -> out bf16 (N, T, 64)"""
+    n, t, _ = qkv.shape
+    L = lib()
+    L.ssie_debug_attention_bf16_scratch_bytes.restype = C.c_size_t
+    out = torch.empty(n, t, 64, device=qkv.device, dtype=torch.bfloat16)
+    nb = L.ssie_debug_attention_bf16_scratch_bytes(n, t) if prepass else 0
+    scratch = torch.empty(max(nb, 16), dtype=torch.uint8, device=qkv.device)
+    check(L.ssie_debug_attention_fwd_bf16(ptr(qkv), ptr(out), n, t, ptr(scratch) if prepass else None, C.c_size_t(nb), stream_ptr()),
+          "ssie_debug_attention_fwd_bf16")
+    return out
 
 
 def attention_bwd(qkv, out, gout, lse):

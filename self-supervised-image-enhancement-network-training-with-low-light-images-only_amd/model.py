@@ -247,7 +247,8 @@ class LowLightEnhance(nn.Module):
             while len(self._plans) >= self.max_cached_plans:
                 self._plans.pop(next(iter(self._plans)))
             plan = H.Plan(x.shape[0], self.input_channels, x.shape[2], x.shape[3], self.coefs(), self._flat, self._gflat)
-            plan.set_graph(os.environ.get("SSIE_GRAPH", "1") != "0")       # train steps of this plan replay one hipGraph
+            # train steps of this plan replay one hipGraph (development: SSIE_DEBUG=1 SSIE_GRAPH=0 runs them eagerly)
+            plan.set_graph(not (H.debug_enabled() and os.environ.get("SSIE_GRAPH") == "0"))
             self._plans[key] = plan
             plan._coefs = tuple(self.coefs().values())
         else:
@@ -279,8 +280,7 @@ class LowLightEnhance(nn.Module):
         (internal: harness and tests)."""
         x = self._f32(input_low)
         plan = self._plan_for(x)
-        # mixed-precision inference (BASELINE.json configs[4]): only outside autograd, training always runs fp32;
-        # band counts the bf16 list cannot take (B+1 not a multiple of 8 after padding) use the fp32 path
+        # mixed-precision inference (BASELINE.json configs[4]): only outside autograd, training always runs fp32
         bf16 = bool(self.bf16_inference) and not torch.is_grad_enabled() and plan.has_bf16()
         plan.enhance_fwd(x, bf16=bf16)
         b = self.input_channels

@@ -8,6 +8,8 @@ writes reference OUTPUTS (data only) to tests/golden/*.npz:
   case_b5_16   N=1 B=5  16x16   default coefs : full R,I,D,S,E, 7 losses, grads (full <=40000 elems, else ::53), params after 1 & 3 Adam steps (::97)
   case_b31_32  N=2 B=31 32x32   JYU coefs     : strided sub-samples + fp64 checksums of R,I,D,S,E, 7 losses, grad norms + small grads (others ::53), params after 1 & 3 steps
   case_b31_64  N=2 B=31 64x64   JYU coefs     : strided sub-samples + fp64 checksums, 7 losses, grad norms
+  case_b64_32  N=2 B=64 32x32   JYU coefs     : the reference's own band count (constructor default model.py:178 and `channels: 64`
+               in all eight shipped configs): strided sub-samples + checksums, 7 losses, grad norms + small grads, params after 1 & 3 steps
   aux          Fourier masks (16/64/128), nearest-upsample index vectors, crop+augment patches
   hsi_raw.mat  a small raw cube written by the reference's utils.save_hsi (utils.py:171-178)
   io           utils.load_hsi (utils.py:36-57) of that file in every normalisation mode (None, self, global with min 238 /
@@ -186,8 +188,12 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "io":
         run_io(ref_utils)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "b64":       # round 4: added without re-writing the older fixtures
+        run_case(ref_model, "case_b64_32", 2, 64, 32, O.JYU_COEFS, full=False)
+        sys.exit(0)
     run_case(ref_model, "case_b5_16", 1, 5, 16, O.DEFAULT_COEFS, full=True)
     run_case(ref_model, "case_b31_32", 2, 31, 32, O.JYU_COEFS, full=False)
     run_case(ref_model, "case_b31_64", 2, 31, 64, O.JYU_COEFS, full=False)
+    run_case(ref_model, "case_b64_32", 2, 64, 32, O.JYU_COEFS, full=False)
     run_aux(ref_model, ref_utils)
     run_io(ref_utils)

@@ -48,6 +48,8 @@ CASES = {
     "b5_16": (1, 5, 16, 16, O.DEFAULT_COEFS),
     "b31_32": (2, 31, 32, 32, O.JYU_COEFS),
     "b31_64": (2, 31, 64, 64, O.JYU_COEFS),
+    "b64_64": (2, 64, 64, 64, O.JYU_COEFS),           # the reference's own band count (model.py:178; every shipped config)
+    "b64_128": (2, 64, 128, 128, O.JYU_COEFS),        # config_outdoor_jyu.yml:7,11-12: batch 2 of 128 x 128 x 64, real launch heuristics
     "b8_32x64": (3, 8, 32, 64, O.JYU_COEFS),
     "b8_24x40": (2, 8, 24, 40, O.JYU_COEFS),
     "b8_20x28": (2, 8, 20, 28, O.JYU_COEFS),          # pyramid 20x28 -> 10x14 -> 5x7 -> 3x4: the odd levels take the general up-sampling adjoint
@@ -170,7 +172,7 @@ def forced_kernels(pkg, request):
 
 @pytest.mark.parametrize("case", list(CASES))
 def test_backward_chain_injected(pkg, case, forced_kernels):
-    if forced_kernels and (case in ("b5_16", "b5_256") or (case == "b256_64" and forced_kernels != "winograd")):
+    if forced_kernels and (case in ("b5_16", "b5_256", "b64_128") or (case == "b256_64" and forced_kernels != "winograd")):
         pytest.skip("forced-kernel variant runs on the mid-size cases only (time); 256 bands: the Winograd / tconv kernels only")
     n, bands, h, w, coefs = CASES[case]
     check_chain(pkg, case, n, bands, h, w, coefs, forced_kernels)
@@ -194,7 +196,7 @@ ONE_HOT = ["c_rec", "c_rf", "c_il", "c_id", "c_f", "c_sp"]
 ONE_HOT_TOL = {"c_rec": 1e-3, "c_sp": 1e-3, "c_rf": 5e-3, "c_il": 5e-3, "c_id": 2e-2, "c_f": 2e-2}
 
 
-@pytest.mark.parametrize("case", ["b31_32", "b31_64", "b8_24x40"])
+@pytest.mark.parametrize("case", ["b31_32", "b31_64", "b8_24x40", "b64_64"])
 @pytest.mark.parametrize("term", ONE_HOT)
 def test_one_hot_coefficients(pkg, case, term):
     H = pkg

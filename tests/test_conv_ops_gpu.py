@@ -87,6 +87,10 @@ def close(got, ref, tol=TOL):
     (64, 257, 3, 1, 16, 32, 2),         # recon (257 = 9 output-channel blocks, ragged last one), sigmoid
     (257, 64, 3, 1, 16, 32, 1),         # the illumination net's conv0 on cat[R, I]
     (256, 64, 9, 1, 16, 16, 0),         # shallow_conv (direct 9 x 9 kernels; the spectral path is a plan-level test)
+    (65, 64, 3, 1, 16, 32, 0),          # 64 bands, the reference's own count (model.py:178): illumination conv0 on cat[R, I] = 65 channels,
+    (64, 65, 3, 1, 16, 32, 2),          # recon with 65 outputs (a ragged third 32-channel block), sigmoid,
+    (64, 64, 9, 1, 16, 16, 0),          # shallow_conv at 64 input channels
+    (64, 32, 3, 1, 18, 22, 1),          # conv0 at 64 bands
 ])
 def test_conv2d_fwd(H, cin, cout, k, stride, h, w, act):
     n = 2
@@ -168,6 +172,9 @@ def _conv_grads(x, wt, stride, g, transposed=False):
     (64, 257, 3, 1, 16, 32),
     (257, 64, 3, 1, 16, 32),
     (256, 64, 9, 1, 16, 16),
+    (65, 64, 3, 1, 16, 32),
+    (64, 65, 3, 1, 16, 32),
+    (64, 64, 9, 1, 16, 16),
 ])
 def test_conv2d_dgrad_wgrad(H, cin, cout, k, stride, h, w):
     n = 2

@@ -118,3 +118,50 @@ def test_32bit_offset_guard(pkg):
     rc = L.ssie_conv2d_dgrad(fake, 64, 0, n_bad, 128, 128, 64, fake, 64, 0, 64, 3, 1, fake, 128, 128, 64, 0, None, 0, 0,
                              fake, ws_bytes, None)
     assert rc == 2, rc
+
+
+def test_polluted_environment_does_not_reach_the_product_loader(pkg, monkeypatch):
+    """stray SSIE_* variables must not change what the product loads or how it launches.  Without
+    SSIE_DEBUG=1 the loader ignores SSIE_HIP_LIB and applies none of the eighteen development switches (a fresh load with a
+    polluted environment resolves the in-tree library and calls no ssie_debug_set_*); the module's plans keep their hipGraph."""
+    H, M = pkg
+    called = []
+
+    class Spy:
+        def __init__(self, real):
+            object.__setattr__(self, "_real", real)
+
+        def __getattr__(self, name):
+            f = getattr(self._real, name)
+            if name.startswith("ssie_debug_set_"):
+                called.append(name)
+            return f
+
+        def __setattr__(self, name, v):
+            setattr(self._real, name, v)
+
+    for env, _ in H._DEBUG_ENV:
+        monkeypatch.setenv(env, "0")
+    monkeypatch.setenv("SSIE_HIP_LIB", "/nonexistent/libssie_other.so")
+    monkeypatch.delenv("SSIE_DEBUG", raising=False)
+    real_cdll = H.C.CDLL
+    loaded = []
+    monkeypatch.setattr(H.C, "CDLL", lambda path: (loaded.append(path), Spy(real_cdll(path)))[1])
+    monkeypatch.setattr(H, "_LIB", None)
+    L = H.lib()
+    assert loaded == [H._build.LIB] and called == []
+    assert b"gfx950" in L.ssie_version()
+    assert not H.debug_enabled()
+    # the same environment WITH the opt-in: the alternate path is taken (and, not existing, refused loudly)
+    monkeypatch.setenv("SSIE_DEBUG", "1")
+    monkeypatch.setattr(H, "_LIB", None)
+    with pytest.raises(H.SsieError):
+        H.lib()
+    monkeypatch.setenv("SSIE_HIP_LIB", H._build.LIB)
+    for env, _ in H._DEBUG_ENV:                     # one harmless switch only (its default value): the setters are process-global
+        monkeypatch.delenv(env, raising=False)
+    monkeypatch.setenv("SSIE_GRAPH", "0")
+    monkeypatch.setattr(H, "_LIB", None)
+    H.lib()
+    assert called == ["ssie_debug_set_graph"]
+    monkeypatch.setattr(H, "_LIB", None)

@@ -19,6 +19,7 @@ CASES = {
     "case_b5_16": (1, 5, 16, O.DEFAULT_COEFS),
     "case_b31_32": (2, 31, 32, O.JYU_COEFS),
     "case_b31_64": (2, 31, 64, O.JYU_COEFS),
+    "case_b64_32": (2, 64, 32, O.JYU_COEFS),         # the reference's own band count (model.py:178; `channels: 64` in all 8 configs)
 }
 
 
@@ -45,7 +46,7 @@ def test_forward_and_losses_match_reference(golden_dir, name):
     assert np.all(np.abs(got - ref) <= 1e-5 * np.abs(ref) + 1e-9), (got, ref)
 
 
-@pytest.mark.parametrize("name", ["case_b5_16", "case_b31_32"])
+@pytest.mark.parametrize("name", ["case_b5_16", "case_b31_32", "case_b64_32"])
 def test_grads_match_reference(golden_dir, name):
     n, bands, hw, coefs = CASES[name]
     g = _load(golden_dir, name)

@@ -21,6 +21,9 @@ CASES = {
     "b5_16": (1, 5, 16, 16, O.DEFAULT_COEFS),
     "b31_32": (2, 31, 32, 32, O.JYU_COEFS),
     "b31_64": (2, 31, 64, 64, O.JYU_COEFS),
+    "b64_32": (2, 64, 32, 32, O.JYU_COEFS),          # the reference's own band count (model.py:178; `channels: 64` in every shipped config):
+    "b64_64": (2, 64, 64, 64, O.JYU_COEFS),          # R|I of 65 channels in a 68-float pixel, recon with a ragged third 32-channel block,
+    "b64_128": (2, 64, 128, 128, O.JYU_COEFS),       # conv0 of the illumination net at Cin = 65; b64_128 = config_outdoor_jyu.yml:7,11-12 (batch 2, 128 x 128 x 64)
     "b8_32x64": (3, 8, 32, 64, O.JYU_COEFS),
     "b31_128": (1, 31, 128, 128, O.JYU_COEFS),       # BASELINE.json configs[1] geometry (one patch of the bench batch)
     "b256_64": (1, 256, 64, 64, O.JYU_COEFS),        # BASELINE.json configs[2]: 256-band cubes
@@ -88,7 +91,7 @@ def forced_kernels(pkg, request):
 @pytest.mark.parametrize("case", list(CASES))
 def test_stagewise_parity(pkg, case, forced_kernels):
     H, _ = pkg
-    if forced_kernels and (case in ("b5_16", "b5_96", "b5_256", "b4_160x288") or (case == "b256_64" and forced_kernels != "winograd")):
+    if forced_kernels and (case in ("b5_16", "b5_96", "b5_256", "b4_160x288", "b64_32", "b64_128") or (case == "b256_64" and forced_kernels != "winograd")):
         pytest.skip("forced-kernel variant runs on the mid-size cases only (time); 256 bands: the Winograd / tconv kernels only")
     n, bands, h, w, coefs = CASES[case]
     plan, table, flat, gflat, P = build_plan(H, n, bands, h, w, coefs)
@@ -197,7 +200,7 @@ def test_side_stream_overlap_is_bit_identical(pkg):
     assert torch.equal(out[0][1], out[1][1])
 
 
-@pytest.mark.parametrize("case", ["b5_16", "b31_32", "b31_64"])
+@pytest.mark.parametrize("case", ["b5_16", "b31_32", "b31_64", "b64_32"])
 def test_golden_reference_outputs(pkg, golden_dir, case):
     """HIP path vs the reference's own outputs (fixtures made by tests/golden/make_golden.py)."""
     H, _ = pkg
@@ -231,7 +234,7 @@ def test_golden_reference_outputs(pkg, golden_dir, case):
 
 
 @pytest.mark.parametrize("fused_tail", [1, 0])
-@pytest.mark.parametrize("n,bands,h,w", [(1, 31, 200, 264), (2, 31, 50, 38), (1, 256, 128, 128), (3, 8, 32, 64)])
+@pytest.mark.parametrize("n,bands,h,w", [(1, 31, 200, 264), (2, 31, 50, 38), (1, 256, 128, 128), (3, 8, 32, 64), (1, 64, 90, 70)])
 def test_enhance_only_ragged_sizes(pkg, n, bands, h, w, fused_tail):
     """Enhance-only path (test/inference entry, model.py:229-234) on sizes that are not multiples of the 16-pixel
     tiles or of 8 (odd pyramid levels: the nearest up-sampling reads ceil-sized levels), and on full-size 256-band cubes.

@@ -6,6 +6,6 @@ for rep in 1 2; do
 for spec in "$@"; do
   v=${spec%%:*}; envs=""; [ "$spec" != "$v" ] && envs=$(echo "${spec#*:}" | tr ',' ' ')
   if [ "$v" = cur ]; then lib=""; else lib=$PWD/tools/_bin/libssie_hip_$v.so; fi
-  r=$(env $envs SSIE_HIP_LIB=$lib timeout -k 10 200 python bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])") || exit 1
+  r=$(env SSIE_DEBUG=1 $envs SSIE_HIP_LIB=$lib timeout -k 10 200 python bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])") || exit 1
   echo "$spec $r"
 done; done

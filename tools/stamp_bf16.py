@@ -10,7 +10,7 @@ ssie.load()
 from ssie_amd import build
 if not os.path.exists(out):
     subprocess.check_call([build.hipcc(), *build.FLAGS, "-DSSIE_STAMP", *extra, "-shared", "-o", out, *build.sources()])
-os.environ["SSIE_HIP_LIB"] = out
+os.environ["SSIE_DEBUG"] = "1"; os.environ["SSIE_HIP_LIB"] = out
 import numpy as np, torch
 from ssie_amd import hostlib as H, model
 import bench
