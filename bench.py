@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path on synthetic hyperspectral cubes (inputs resident in HBM).
 
-  python bench.py --gpus N --steps K --warmup W [--workload train31|train256|infer1024_bf16|infer1024_f32]
+  python bench.py --gpus N --steps K --warmup W [--workload train31|train64|train256|infer1024_bf16|infer1024_f32]
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 workloads (BASELINE.json configs):
@@ -9,14 +9,17 @@ workloads (BASELINE.json configs):
                   buffer per step): full self-supervised train step (forward, six losses, hand-derived backward, fused Adam),
                   batch 32 per GPU of 128x128x31 patches, fp32.  THE headline metric.
   train256        configs[2]: the same step on 128x128x256-band cubes, batch 32 per GPU, fp32
+  train64         the reference's SHIPPED configuration (config_outdoor_jyu.yml:7,11-12: 64 bands, batch 2, 128x128 patches): the
+                  same step at the reference's own band count and batch (default --batch 2 for this workload)
   infer1024_bf16  configs[4]: enhance-only forward (model.py:229-234) of one 1x31x1024x1024 cube, bf16 storage + bf16 MFMA
                   (fp32 accumulate, fp32 outputs), whole image in one pass; a "step" = one image
   infer1024_f32   the same forward in fp32 (what the bf16 line is compared with)
 
-The default invocation (`python bench.py`, 1 GPU, headline workload) also runs SHORT passes of the other two single-GPU BASELINE
-configs after the headline has been timed - train256 (3 warm-up + 5 steps) and infer1024_bf16 (5 + 20) - and attaches them
-as `"also": [{workload, value, unit, ms_per_step, parity, roofline, ...}]`; the headline fields are untouched (`--no-also`
-skips them).  `host_ms_per_step` = host time spent INSIDE one train_step call of the timed region (Python + launch enqueue,
+The default invocation (`python bench.py`, 1 GPU, headline workload) also runs SHORT passes of the other single-GPU
+configurations after the headline has been timed - train64 at batch 2 (5 warm-up + 20 steps), train256 (3 + 10) and infer1024_bf16
+(5 + 20) - and attaches them as `"also": [{workload, value, unit, ms_per_step, parity, roofline, cpu_baseline, ...}]`; the headline
+fields are untouched (`--no-also` skips them).  `harness_patches_per_s` (headline line) = the same N = 32 step driven the way
+`train_model` drives it: host-drawn crops, on-device crop + 8-way augmentation from resident cubes, train_step, lagged loss read-back.  `host_ms_per_step` = host time spent INSIDE one train_step call of the timed region (Python + launch enqueue,
 no synchronisation; minimum over the steps = a step that did not block on a full HIP queue): what one CPU core must sustain
 per step to keep a GPU fed.
 
@@ -78,7 +81,7 @@ def dominant_traffic(kernel_substr, workload):
     command, MI355X_MICROARCH.md HBM section) from the committed profile of THIS round and THIS workload (final pass first,
     then the mid-round one); PMC counters cannot be read from inside the process.  -> (bytes or None, kernel name, source file)"""
     try:
-        for tag in ("r03_final", "r03_mid", "r02_final"):
+        for tag in ("r04_final", "r04_mid", "r03_final"):
             f = os.path.join(ROOT, "profiles", f"{tag}_{workload}_hbm_traffic.json")
             if not os.path.exists(f):
                 continue
@@ -92,7 +95,9 @@ def dominant_traffic(kernel_substr, workload):
     return None, None, None
 
 
-def class_table(agg, reps):
+def class_table(agg, reps, class_bytes=None):
+    """class_bytes: {class: algorithmic HBM bytes per step} (ssie_plan_class_bytes / ssie_plan_op_bytes: every operand read once,
+    every result written once) -> algorithmic GB/s and fraction of the 8 TB/s HBM peak per class"""
     out = {}
     for k, v in agg.items():
         ms, fl, cnt = v[0] / reps, v[1] / reps, v[2] // reps
@@ -100,8 +105,63 @@ def class_table(agg, reps):
              "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if fl > 0 and ms > 0 else None}
         if "winograd" in k and fl > 0 and ms > 0:       # "tflops" = direct-convolution FLOPs / time; the MFMAs execute 16/36 of them
             e["executed_mfma_tflops"] = round(fl * WINO_EXECUTED / (ms * 1e-3) / 1e12, 2)
+        b = (class_bytes or {}).get(k, 0.0)
+        if b > 0 and ms > 0:
+            e["algorithmic_GBps"] = round(b / (ms * 1e-3) / 1e9, 1)
+            e["frac_of_hbm_peak"] = round(b / (ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 3)
         out[k] = e
     return out
+
+
+def ssim_first_patch(S_hip, S_ref):
+    """SSIM of the build's enhanced cube against the oracle's on the first patch, with the harness's own definition of the
+    reference's call (metrics.py:16-19: the (H,W,C) cube fed as a (1,H,W,C) image, i.e. H in the channel role; torchmetrics defaults).
+    torchmetrics is not importable here and the reference holds no fixture: the DEFINITION is parity-unpinned."""
+    from ssie_amd import harness
+    a = S_hip[0].permute(1, 2, 0).contiguous(); b = S_ref[0].permute(1, 2, 0).contiguous()
+    return float(harness.ssim(a, b, 1.0))
+
+
+def time_harness_loop(args, torch, hostlib, net, dev, step_only_value):
+    """The step as `harness.train_model` drives it (model.py:300-319): crops drawn on the host in the reference's RNG order,
+    crop + 8-way augmentation on the device from cubes resident in HBM (records through a pinned two-slot ring), train_step, the
+    seven loss scalars read back with a one-step lag.  Same N, bands, patch size, warm-up and step count as the timed region."""
+    import numpy as np
+    from ssie_amd import harness
+    bands, hw, batch = args.bands, args.hw, args.batch
+    ncubes, side = 8, hw + 72
+    cubes = [synth(1, bands, side, 1000 + i, dev)[0].permute(1, 2, 0).contiguous() for i in range(ncubes)]     # (H, W, C) resident cubes
+    shapes = [tuple(c.shape) for c in cubes]
+    rng = np.random.RandomState(41)
+    lag = harness.LaggedScalars(2)
+    staging = [torch.empty(batch * harness.ctypes_sizeof_crop(), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+    seen = []
+
+    def one(b):
+        crops = harness.draw_crops(ncubes, shapes, b, batch, hw, rng)
+        xb = hostlib.assemble_batch(cubes, crops, hw, bands, staging=staging[b & 1])
+        seen.extend(lag.push(net.train_step(xb, 1), b))
+
+    for b in range(args.warmup):
+        one(b)
+    seen.extend(lag.drain())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    host = []
+    for b in range(args.warmup, args.warmup + args.steps):
+        h0 = time.perf_counter()
+        one(b)
+        host.append(time.perf_counter() - h0)
+    seen.extend(lag.drain())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert len(seen) == args.warmup + args.steps and all(np.isfinite(v).all() for _, v in seen)
+    v = batch * args.steps / dt
+    return {"harness_patches_per_s": round(v, 2), "harness_ms_per_step": round(dt / args.steps * 1e3, 3),
+            "harness_over_step_only": round(v / step_only_value, 4),
+            "harness_host_ms_per_step": round(min(host) * 1e3, 3),
+            "harness_what": f"{args.steps} steps of draw_crops + assemble_batch (device crop + augment from {ncubes} resident "
+                            f"{side}x{side}x{bands} cubes) + train_step + LaggedScalars, batch {batch}"}
 
 
 def run_train(args, torch, dist, hostlib, model, world, rank, dev):
@@ -158,6 +218,9 @@ def run_train(args, torch, dist, hostlib, model, world, rank, dev):
         # the frequency domain and the stride-1 3x3 layers on Winograd F(2x2,3x3), which execute a fraction of these FLOPs
         out["step_algorithmic_tflops_per_gpu"] = round(value / world * gf / 1e3, 2)
 
+    if getattr(args, "harness_loop", False) and world == 1:
+        out.update(time_harness_loop(args, torch, hostlib, net, dev, value))
+
     if rank == 0 and not args.no_roofline:
         plan = net._plan_for(x)
         agg = None
@@ -180,16 +243,15 @@ def run_train(args, torch, dist, hostlib, model, world, rank, dev):
                            "launches_per_step": cnt // reps, "avg_launch_ms": round(ms / cnt, 4),
                            "algorithmic_gflop_per_step": round(fl / reps / 1e9, 1),
                            "executed_fraction_of_algorithmic_flops": round(executed, 4)}
-        kc = class_table(agg, reps)
-        # HBM-bound classes: algorithmic bytes / device time (fused loss ~7 cubes + planes per patch; the Fourier
-        # term reads x, S and read-modify-writes gS; Adam 7 floats per parameter)
-        cube = batch * hw * hw * ((bands + 3) // 4 * 4) * 4
-        hbm_alg = {"loss_direct": 7 * cube + 5 * batch * hw * hw * 4, "fft_loss_kernel": 4 * cube}
-        for k, b in hbm_alg.items():
-            if kc.get(k, {}).get("ms_per_step"):
-                kc[k]["algorithmic_GBps"] = round(b / (kc[k]["ms_per_step"] * 1e-3) / 1e9, 1)
-                kc[k]["frac_of_hbm_peak"] = round(b / (kc[k]["ms_per_step"] * 1e-3) / 1e12 / PEAK_HBM_TBS, 3)
-        out["kernel_classes"] = kc
+        # algorithmic bytes per class from the plan's own op lists (every operand read once, every result written once; SURVEY
+        # 8(d): fused loss 7 cubes + 5 planes per patch, the Fourier term reads x, S and read-modify-writes gS)
+        import ctypes as C
+        nk = len(hostlib.Plan.KINDS)
+        cb = (C.c_double * nk)()
+        hostlib.lib().ssie_plan_class_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        hostlib.check(hostlib.lib().ssie_plan_class_bytes(plan.h, cb), "ssie_plan_class_bytes")
+        out["kernel_classes"] = class_table(agg, reps, {k: cb[i] for i, k in enumerate(hostlib.Plan.KINDS)})
+        out["launches_per_step"] = sum(v[2] for v in agg.values()) // reps
     if world > 1:
         sync_all()
 
@@ -207,19 +269,22 @@ def run_train(args, torch, dist, hostlib, model, world, rank, dev):
             Sh = first[1].cpu()
             out["parity"] = {"what": f"first train step of the timed N={batch} plan vs the CPU oracle on the same batch",
                              "psnr_enhanced_vs_cpu_oracle_db": round(O.psnr(Sh, outs[3]), 1),
+                             "ssim_enhanced_vs_cpu_oracle": round(ssim_first_patch(Sh, outs[3]), 9),
+                             "ssim_definition": "harness.ssim on patch 0 (own restatement of metrics.py:16-19; torchmetrics absent: unpinned)",
                              "max_abs_S": float((Sh - outs[3]).abs().max()),
                              "max_rel_err_7_losses": float(max(rel.values())),
                              "total_loss_hip": got[0], "total_loss_oracle": vals["total_loss"]}
             del outs
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not getattr(args, "parity_only", False):
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from collections import OrderedDict
         from oracle import ssie_oracle as O
         P = OrderedDict((k, v.clone()) for k, v in P0.items())
         xb = x[:2].cpu()
         st = O.AdamState(P)
         O.train_step(P, xb, JYU_O, st)                          # warm-up
+        budget = 4.0 if getattr(args, "parity_only", False) else 12.0     # the also[] entries take a shorter sample of the same loop
         t0 = time.perf_counter(); n = 0
-        while n < 2 or (time.perf_counter() - t0 < 12.0 and n < 400):
+        while n < 2 or (time.perf_counter() - t0 < budget and n < 400):
             P, *_ = O.train_step(P, xb, JYU_O, st); n += 1
         cdt = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": round(2 * n / cdt, 3), "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
@@ -302,17 +367,37 @@ def run_infer(args, torch, hostlib, model, dev):
         t_mfma = exec_gflop / 1e3 / peak * 1e3                  # ms
         t_hbm = alg_bytes / (PEAK_HBM_TBS * 1e12) * 1e3
         traffic, tk, tsrc = dominant_traffic("conv_fprop_bf16" if bf16 else "conv_wino_kernel" if "winograd" in dom else "conv_fprop_v2", args.workload)
-        out["roofline"] = {"kernel": dom, "bound": "mfma" if t_mfma >= t_hbm else "hbm", "achieved": round(ach, 2), "peak": peak,
-                           "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_kernel": tk, "traffic_source": tsrc,
-                           "launches_per_step": dcnt // reps, "avg_launch_ms": round(dms / dcnt, 4),
-                           "algorithmic_gflop_per_step": round(dfl / reps / 1e9, 1),
-                           "executed_fraction_of_algorithmic_flops": round(executed, 4)}
+        # algorithmic HBM bytes per launch from the plan's own op list (operands read once, results written once at storage precision)
+        ob = (C.c_double * cap)()
+        L.ssie_plan_op_bytes.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int]
+        nb = L.ssie_plan_op_bytes(plan.h, int(bf16), ob, cap)
+        assert nb == n, (nb, n)
+        cbytes = {}
+        for i in range(n):
+            k = hostlib.Plan.KINDS[kinds[i]]
+            cbytes[k] = cbytes.get(k, 0.0) + ob[i]
+        hbm_bound = t_hbm > t_mfma
+        if hbm_bound:
+            # the forward's binding floor is HBM: the dominant class is priced in GB/s of ITS algorithmic bytes against the HBM peak
+            gbps = cbytes[dom] / (dms / reps * 1e-3) / 1e9
+            out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
+                               "frac": round(gbps / (PEAK_HBM_TBS * 1e3), 4), "traffic": traffic, "traffic_kernel": tk, "traffic_source": tsrc,
+                               "launches_per_step": dcnt // reps, "avg_launch_ms": round(dms / dcnt, 4),
+                               "algorithmic_bytes_per_step": int(cbytes[dom]), "class_mfma_tflops": round(ach, 2),
+                               "class_frac_of_mfma_peak": round(ach / peak, 4)}
+        else:
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
+                               "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_kernel": tk, "traffic_source": tsrc,
+                               "launches_per_step": dcnt // reps, "avg_launch_ms": round(dms / dcnt, 4),
+                               "algorithmic_gflop_per_step": round(dfl / reps / 1e9, 1),
+                               "executed_fraction_of_algorithmic_flops": round(executed, 4)}
         step_ms = dt / args.steps * 1e3
         out["floors"] = {"mfma_ms": round(t_mfma, 3), "executed_gflop": round(exec_gflop, 1), "hbm_ms": round(t_hbm, 3), "algorithmic_hbm_GB": round(alg_bytes / 1e9, 2),
                          "binding": "mfma" if t_mfma >= t_hbm else "hbm",
                          "frac_of_binding_floor": round(max(t_mfma, t_hbm) / step_ms, 4),
                          "whole_image_tflops": round(gflop / step_ms, 1), "whole_image_GBps": round(alg_bytes / step_ms / 1e6, 1)}
-        out["kernel_classes"] = class_table(agg, reps)
+        out["kernel_classes"] = class_table(agg, reps, cbytes)
+        out["launches_per_step"] = n
     if not args.no_cpu_baseline:
         # TEST-INFRASTRUCTURE import: the CPU oracle as PSNR checker and timed baseline
         from oracle import ssie_oracle as O
@@ -329,7 +414,10 @@ def run_infer(args, torch, hostlib, model, dev):
             cdt = time.perf_counter() - t0
         Sh = S_dev.cpu()
         out["parity"] = {"what": "enhanced cube S of the timed forward vs the fp32 CPU oracle (whole image)",
-                         "psnr_enhanced_vs_cpu_oracle_db": round(O.psnr(Sh, So), 1), "max_abs_S": float((Sh - So).abs().max())}
+                         "psnr_enhanced_vs_cpu_oracle_db": round(O.psnr(Sh, So), 1),
+                         "ssim_enhanced_vs_cpu_oracle": round(ssim_first_patch(Sh, So), 9),
+                         "ssim_definition": "harness.ssim on the image (own restatement of metrics.py:16-19; torchmetrics absent: unpinned)",
+                         "max_abs_S": float((Sh - So).abs().max())}
         out["cpu_baseline"] = {"value": round(n / cdt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
                                "sample": f"{n} whole-image forwards of 1x{bands}x{hw}x{hw} on the CPU oracle (fp32), {cdt:.1f} s"}
     return out
@@ -340,8 +428,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="train31", choices=["train31", "train256", "infer1024_bf16", "infer1024_f32"])
-    ap.add_argument("--batch", type=int, default=32, help="patches per GPU (train workloads)")
+    ap.add_argument("--workload", default="train31", choices=["train31", "train64", "train256", "infer1024_bf16", "infer1024_f32"])
+    ap.add_argument("--batch", type=int, default=None, help="patches per GPU (train workloads; default 32, train64: 2 = the reference's batch)")
+    ap.add_argument("--harness-loop", action="store_true", help="also time the step as harness.train_model drives it (on by default for the default invocation)")
     ap.add_argument("--bands", type=int, default=None)
     ap.add_argument("--hw", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -350,7 +439,9 @@ def main():
     args = ap.parse_args()
     train = args.workload.startswith("train")
     if args.bands is None:
-        args.bands = 256 if args.workload == "train256" else 31
+        args.bands = 256 if args.workload == "train256" else 64 if args.workload == "train64" else 31
+    if args.batch is None:
+        args.batch = 2 if args.workload == "train64" else 32
     if args.hw is None:
         args.hw = 128 if train else 1024
     args.warmup = max(args.warmup, 1)
@@ -381,22 +472,24 @@ def main():
     assert hostlib.lib().ssie_device_ok() == 1, "bench.py needs a gfx950 (MI355X) device"
 
     defaults = args.workload == "train31" and args.bands == 31 and args.hw == 128 and args.batch == 32
+    if defaults and world == 1 and not launched and not args.no_also:
+        args.harness_loop = True
     if train:
         out = run_train(args, torch, dist, hostlib, model, world, rank, dev)
         out["rccl_group"] = bool(launched)
     else:
         out = run_infer(args, torch, hostlib, model, dev)
     if defaults and world == 1 and not launched and not args.no_also and not args.no_cpu_baseline:
-        # BASELINE configs[2] and configs[4] beside the headline (VERDICT r2 missing 2): short passes, each with its own parity leg
-        # (CPU oracle as checker only, its timing loop skipped) and roofline; the headline fields above are already final
+        # the reference's shipped configuration (64 bands, batch 2) and BASELINE configs[2] / configs[4] beside the headline: short
+        # passes, each with its own parity leg, roofline and a (shorter) cpu_baseline sample; the headline fields above are already final
         import copy
         import gc
         also = []
-        for wl, steps, warm in (("train256", 5, 3), ("infer1024_bf16", 20, 5)):
+        for wl, steps, warm in (("train64", 20, 5), ("train256", 10, 3), ("infer1024_bf16", 20, 5)):
             gc.collect(); torch.cuda.empty_cache()
             a = copy.copy(args)
-            a.workload, a.steps, a.warmup, a.parity_only = wl, steps, warm, True
-            a.bands, a.hw, a.batch = (256, 128, 32) if wl == "train256" else (31, 1024, 1)
+            a.workload, a.steps, a.warmup, a.parity_only, a.harness_loop = wl, steps, warm, True, False
+            a.bands, a.hw, a.batch = (256, 128, 32) if wl == "train256" else (64, 128, 2) if wl == "train64" else (31, 1024, 1)
             t0 = time.perf_counter()
             try:
                 o = run_train(a, torch, dist, hostlib, model, 1, 0, dev) if wl.startswith("train") else run_infer(a, torch, hostlib, model, dev)

@@ -21,6 +21,11 @@ int ssie_plan_profile_ops(void* plan, const float* x, const long* strides4, void
 /* per-launch timing of one op list; which = 0 fp32 enhance forward, 1 = bf16 enhance forward */
 int ssie_plan_profile_list(void* plan, const float* x, const long* strides4, void* stream, int which,
                            double* ms, double* flops, int* kinds, int cap, char* tags, int tags_cap);
+/* algorithmic HBM bytes per launch (each operand read once, each result written once; 0 where none is stated) in the order of the
+ * matching profile call: which = 0 / 1 = the lists of ssie_plan_profile_list, 2 = the train step of ssie_plan_profile_ops; returns
+ * the op count (or -error).  ssie_plan_class_bytes: the same summed per kernel class of the train step (SSIE_NKINDS entries) */
+int ssie_plan_op_bytes(void* plan, int which, double* bytes, int cap);
+int ssie_plan_class_bytes(void* plan, double* bytes);
 /* launches per op list: {enhance forward, second decomposition pass, loss + backward} */
 int ssie_plan_num_ops(void* plan, int* counts3);
 

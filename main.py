@@ -8,7 +8,9 @@ Same keys, same priority (CLI > YAML > default), same derived directories.  Diff
   * `train_and_test` works on Linux (the reference writes `Decomposition_<ts>` but reads `decomposition_<ts>`, main.py:87);
   * in `test` phase the checkpoint timestamp comes from `--timestamp` (the reference hard-codes a literal, main.py:78-80);
   * exceptions propagate with a non-zero exit code (the reference swallows them, main.py:266-270);
-  * multi-GPU: launch under `python -m torch.distributed.run --nproc-per-node N main.py ...` (patches sharded per rank).
+  * multi-GPU: launch under `python -m torch.distributed.run --nproc-per-node N main.py ...`; `--dp_mode shard` splits ONE batch of
+    `batch_size` over the ranks (bit-comparable with one GPU), `per_rank` gives every rank `batch_size` patches from its own RNG
+    stream (seed + rank; the reference's batch 1-2 on 8 GPUs), `auto` (default) shards when batch_size divides by the rank count.
 """
 import argparse
 import glob
@@ -33,6 +35,9 @@ DEFAULTS = {
     "c_loss_fourier": 0.2, "c_loss_spectral_cons": 1., "alpha_i_smooth_low": 1., "alpha_i_smooth_delta": 10.,
     "save_reflectance": False, "save_illumination": False, "save_i_delta": False, "bf16_inference": 0, "model_name": "no_name_model",
     "pretrained_model": "", "freeze_decom_epochs": 0,
+    # extra key (the reference is single-process): how `batch_size` is read under torch.distributed.run - "shard" = one global batch
+    # split over the ranks, "per_rank" = batch_size patches per rank from per-rank RNG streams, "auto" = shard when it divides
+    "dp_mode": "auto",
 }
 
 
@@ -118,7 +123,7 @@ def main(args):
     if args.phase in ("train", "train_and_test"):
         harness.train_model(net, args.train_data, args.eval_data, args.batch_size, args.patch_size, args.epoch,
                             args.model_ckpt_dir, args.eval_result_dir, args.eval_every_epoch, args.label_dir,
-                            mat_key=args.mat_key, normalization=args.normalization)
+                            mat_key=args.mat_key, normalization=args.normalization, dp_mode=args.dp_mode, seed=args.seed_value)
     if args.phase in ("test", "train_and_test") and rank == 0:
         files = sorted(glob.glob(os.path.join(args.test_data, "*.*")))
         print("Found test files:", files)

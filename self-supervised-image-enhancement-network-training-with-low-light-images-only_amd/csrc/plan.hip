@@ -31,6 +31,7 @@ enum { K_FPROP2 = 0, K_FPROP1, K_WGRAD, K_WGRAD_REDUCE, K_COLSUM, K_PACK, K_LOSS
 enum { SLAB_NONE = 0, SLAB_WRITE = 1, SLAB_READ = 2 };
 struct Fn {
     FnT fn; int kind; double flops; std::string tag;
+    double bytes = 0.0;  // algorithmic HBM bytes of the launch: every operand tensor read once, every result written once (0 = not stated)
     int slab = 0;       // which of the two slab areas
     int slab_use = SLAB_NONE;
     Fn(FnT f, int k = K_ELEMENTWISE, double fl = 0.0, std::string t = "", int sl = 0, int use = SLAB_NONE)
@@ -249,12 +250,28 @@ struct Builder {
         const double fl = 2.0 * p.N * p.Ho * p.Wo * (double)p.Cout * k_real * p.ntaps;
         char tag[96];
         snprintf(tag, sizeof(tag), "%sconv k%d->n%d taps%d si%d so%d %dx%d", p.wino ? "winograd " : p.tconv ? "transposed (4 classes) " : "", k_real, p.Cout, p.ntaps, p.si, p.so, p.Ho, p.Wo);
+        // algorithmic bytes: each source's physical pixels (an up-sampled source is read at ITS resolution) x the channels taken, the
+        // output positions of this launch x real output channels, the fused epilogue operands, the packed weights
+        const double ein = h16 ? 2.0 : 4.0, eout = (h16 && p.out_bf16) ? 2.0 : 4.0;
+        double by = 0.0;
+        for (int s = 0; s < p.nsrc; ++s) {
+            const double hs = p.src[s].Hs < p.Hv ? p.src[s].Hs : p.Hv, ws = p.src[s].Ws < p.Wv ? p.src[s].Ws : p.Wv;
+            by += (double)p.N * hs * ws * p.src[s].C * ein;
+        }
+        const double opos = (double)p.N * (p.tconv ? 4.0 : 1.0) * p.Ho * p.Wo;
+        by += opos * p.Cout * eout * (p.accumulate ? 2.0 : 1.0);
+        if (p.out2) by += opos * p.Cout * (h16 ? 2.0 : 4.0);
+        if (p.addsrc) by += opos * p.Cout * ein;
+        if (p.mask_y) by += opos * p.Cout * 4.0;
+        by += (double)k_real * p.Cout * p.ntaps * ein;
         if (h16) {
             std::string t16 = std::string("bf16 ") + tag;
             ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_fprop_bf16(p, st); }, p.Cout_pad % 64 == 0 ? K_FPROP2 : K_FPROP1, fl, t16));
+            ops.back().bytes = by;
             return;
         }
         ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_fprop(p, st); }, p.wino ? K_WINO : p.Cout_pad % 64 == 0 ? K_FPROP2 : K_FPROP1, fl, tag));
+        ops.back().bytes = by;
     }
     // bf16 list: which outputs stay fp32 (API outputs and the attention operands)
     static bool out_is_f32(const char* out) { return !strcmp(out, "RL_1") || !strcmp(out, "qkv") || !strcmp(out, "D"); }
@@ -398,7 +415,12 @@ struct Builder {
         char tag[96];
         snprintf(tag, sizeof(tag), "%swgrad ci%d co%d taps%d si%d %dx%d slices%d", p.wino ? "winograd " : "", creal, cout, T, stride, Ho, Wo, p.nslices);
         ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_wgrad(p, st); }, p.wino ? K_WGRAD_WINO : K_WGRAD, fl, tag, sl, SLAB_WRITE));
+        {   // input at its physical resolution + output gradient, read once each; partial slabs written once ...
+            const double hs = x.Hs < Hv ? x.Hs : Hv, ws = x.Ws < Wv ? x.Ws : Wv;
+            ops.back().bytes = 4.0 * ((double)pl.N * nbatch * (hs * ws * creal + (double)Ho * Wo * cout) + (double)need + (double)bneed);
+        }
         ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, p.nslices, p.ntaps, p.ci_pad, p.co_pad, creal, cout, dw, s_co, T, 1, bslab, db, 1, st); }, K_WGRAD_REDUCE, 0.0, "", sl, SLAB_READ));
+        ops.back().bytes = 4.0 * ((double)need + (double)bneed + 2.0 * (double)creal * cout * T);   // ... and read once by the reduction (dW read-modify-write)
         return 0;
     }
 
@@ -419,6 +441,7 @@ struct Builder {
         const int ycs = y ? pl.bi(y).cs : 0, scs = sb.cs, dcs = db.cs;
         const long npix = (long)sb.N * sb.H * sb.W;
         ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_mask_axpy(sp, scs, yp, ycs, mode, dp, dcs, npix, C, accumulate, st); }, K_ELEMENTWISE, 0.0, std::string("mask_axpy ") + src + "->" + dst));
+        ops.back().bytes = 4.0 * npix * C * (2.0 + (y ? 1.0 : 0.0) + (accumulate ? 1.0 : 0.0));
     }
 
     // ---- frequency-domain 9 x 9 convolution (shallow_conv), spectral_conv.hip ----
@@ -475,6 +498,7 @@ struct Builder {
         const float* sp = pl.buf(src); float* dp = pl.buf(dst);
         const int scs = pl.bi(src).cs, dcs = db.cs, Hs = db.H, Ws = db.W, N = pl.N;
         ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_upsample_adjoint(sp, Hv, Wv, scs, dp, Hs, Ws, dcs, N, 64, accumulate, st); }, K_ELEMENTWISE, 0.0, "upsample_adjoint"));
+        ops.back().bytes = 4.0 * N * 64.0 * ((double)Hv * Wv + (double)Hs * Ws * (accumulate ? 2.0 : 1.0));
     }
 };
 
@@ -522,6 +546,10 @@ void push_tail(Builder& b, std::vector<Fn>& ops)
     const double fl = 2.0 * N * H * W * (192.0 * 64 + 64.0 * 9);      // algorithmic FLOPs of the two layers it replaces
     ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_tail(d1, d2, d3, h16, N, H, W, H2, W2, H4, W4, wc, RL, rl, D, 4, S, cx, B, st); },
                      K_ELEMENTWISE, fl, "fused tail: fusion 1x1 + final 3x3 + compose"));
+    {   // reads d1, d2, d3 (storage precision) and R|I (fp32), writes I_delta and S (fp32)
+        const double ea = h16 ? 2.0 : 4.0;
+        ops.back().bytes = (double)N * (64.0 * ea * ((double)H * W + (double)H2 * W2 + (double)H4 * W4) + (double)H * W * 4.0 * (B + 1 + 1 + B));
+    }
 }
 
 int build_illum_fwd(Builder& b, std::vector<Fn>& ops, bool fused_tail = false)
@@ -545,8 +573,11 @@ int build_illum_fwd(Builder& b, std::vector<Fn>& ops, bool fused_tail = false)
             // pre-converted bf16 keys / values go into "gqkv" (a backward-pass tensor: idle during the enhance-only forward)
             float* kvs = pl.buf("gqkv"); const size_t kvs_bytes = (size_t)N * T * 192 * sizeof(float);
             ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_attn_fwd_bf16(qkv, 192, aoh, 64, N, T, st, kvs, kvs_bytes); }, K_ATTN, 4.0 * N * 4 * (double)T * T * 16));
-        } else
+            ops.back().bytes = (double)N * T * (192.0 * 4 + 64.0 * 2);
+        } else {
             ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_attn_fwd(qkv, 192, ao, 64, lse, N, T, st); }, K_ATTN, 4.0 * N * 4 * (double)T * T * 16));
+            ops.back().bytes = (double)N * T * (192.0 + 64.0 + 4.0) * 4;
+        }
     }
     CK(b.conv(ops, layer(pl, i + "attn.ff_linear1"), {b.src("ao", 64, H8, W8)}, H8, W8, 1, "f1", ACT_RELU));
     CK(b.conv(ops, layer(pl, i + "attn.ff_linear2"), {b.src("f1", 64, H8, W8)}, H8, W8, 1, "t3", ACT_NONE, "a3"));
@@ -563,11 +594,13 @@ int build_illum_fwd(Builder& b, std::vector<Fn>& ops, bool fused_tail = false)
         const int N = pl.N;
         ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_skinny_fwd(fp, w, bi, D, 4, N, H, W, st); }, K_ELEMENTWISE,
                          2.0 * N * H * W * 64.0 * 9, "final_conv fwd (VALU)"));
+        ops.back().bytes = 4.0 * N * H * W * 65.0;
     }
     if (!b.dry) {
         const float* RL = pl.buf("RL_1"); const float* D = pl.buf("D"); float* S = pl.buf("S");
         const int rl = pl.CRL, cx = pl.CX, B = pl.B; const long npix = (long)pl.N * H * W;
         ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_compose(RL, rl, D, 4, S, cx, npix, B, st); }, K_ELEMENTWISE, 0.0, "compose"));
+        ops.back().bytes = 4.0 * npix * (2.0 * B + 2.0);
     }
     return 0;
 }
@@ -661,7 +694,9 @@ int build_illum_bwd(Builder& b, std::vector<Fn>& ops)
         const int N = pl.N;
         const double fl = 2.0 * N * H * W * 64.0 * 9;
         ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_skinny_wgrad(fp, gD, 4, part, dw, db, N, H, W, st); }, K_ELEMENTWISE, fl, "final_conv wgrad (VALU)"));
+        ops.back().bytes = 4.0 * N * H * W * 65.0;
         ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_skinny_dgrad(gD, 4, w, Gf, N, H, W, st); }, K_ELEMENTWISE, fl, "final_conv dgrad (VALU)"));
+        ops.back().bytes = 4.0 * N * H * W * 65.0;
     }
     // feature_fusion is a 1 x 1 convolution over cat[up(d1), up(d2), d3] (model.py:169-173).  A 1 x 1 convolution commutes with
     // nearest up-sampling, so the gradients of the d1 / d2 parts are taken at THEIR resolution from the up-sampling adjoint of Gf
@@ -748,12 +783,14 @@ int build_all(Plan& pl, bool dry)
         lp.partials = pl.ws + pl.lpart_off;
         const int nblk = pl.loss_blocks;
         ops.push_back(Fn([lp, nblk](hipStream_t st) { return ssie_launch_loss_direct(lp, nblk, st); }, K_LOSS));
+        ops.back().bytes = 4.0 * N * H * W * (7.0 * B + 5.0);       // reads x, R|I, S, R_enh, D; writes gRL, gS, G8, gD
         FftParams fp; memset(&fp, 0, sizeof(fp));
         fp.x = lp.x; fp.x_cs = lp.x_cs; fp.S = lp.S; fp.s_cs = lp.s_cs; fp.gS = lp.gS; fp.mask = (const uint8_t*)(pl.ws + pl.mask_off);
         fp.N = N; fp.B = B; fp.H = H; fp.W = W; ssie_fft_set_logs(fp);
         fp.ws = pl.ws + pl.fftws_off; fp.ws_floats = pl.fftws_floats; fp.npartials = pl.fft_blocks;
         fp.scale_g = (float)(pl.coefs[4] / (n * c * h * w)); fp.inv_n0 = lp.inv_n0; fp.partials = pl.ws + pl.fpart_off;
         ops.push_back(Fn([fp](hipStream_t st) { return ssie_launch_fft_loss(fp, st); }, K_FFT));
+        ops.back().bytes = 4.0 * N * H * W * 4.0 * B;               // reads x and S, read-modify-writes gS
         const float* lpart = pl.ws + pl.lpart_off; const float* fpart = pl.ws + pl.fpart_off; float* scal = pl.ws + pl.scal_off;
         const int nf = pl.fft_blocks;
         float cf[6] = {pl.coefs[0], pl.coefs[1], pl.coefs[2], pl.coefs[3], pl.coefs[4], pl.coefs[5]};
@@ -766,6 +803,7 @@ int build_all(Plan& pl, bool dry)
         const float* D = pl.buf("D"); float* gD = pl.buf("gD");
         const int cx = pl.CX, rl = pl.CRL, B = pl.B; const long npix = (long)pl.N * pl.H * pl.W;
         ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_product_node(gS, cx, RL, gRL, rl, D, gD, 4, npix, B, st); }, K_ELEMENTWISE, 0.0, "product_node"));
+        ops.back().bytes = 4.0 * npix * (B + (B + 1.0) + 2.0 * (B + 1.0) + 1.0 + 2.0);      // gS, R|I, gRL read-modify-write, D, gD read-modify-write
     }
     CK(build_illum_bwd(b, ops));
     b.mask_axpy(ops, "gRL", "RL_1", MASK_SIGMOID, "G8", pl.B + 1, 0);
@@ -1177,6 +1215,33 @@ extern "C" int ssie_plan_profile_list(void* h, const float* x, const long* strid
     for (auto& e : ev) hipEventDestroy(e);
     if (tags && tags_cap > 0) { strncpy(tags, all.c_str(), tags_cap - 1); tags[tags_cap - 1] = 0; }
     return (int)seq.size();
+}
+
+// algorithmic HBM bytes per launch (each operand read once, each result written once; 0 where a launch states none), in the
+// order of the matching profile call: which = 0 / 1 = the lists of ssie_plan_profile_list, 2 = the train step of ssie_plan_profile_ops
+extern "C" int ssie_plan_op_bytes(void* h, int which, double* bytes, int cap)
+{
+    Plan* pl = (Plan*)h;
+    if (!pl || !pl->bound || !bytes) return -SSIE_E_ARG;
+    std::vector<const Fn*> seq;
+    if (which == 2) {
+        for (auto& f : pl->fwd) seq.push_back(&f);
+        for (auto& f : pl->pass2) seq.push_back(&f);
+        for (auto& f : pl->lossbwd) seq.push_back(&f);
+    } else for (auto& f : (which == 1 ? pl->fwd16 : (pl->fwdi.empty() ? pl->fwd : pl->fwdi))) seq.push_back(&f);
+    if ((int)seq.size() > cap) return -SSIE_E_WORKSPACE;
+    for (size_t i = 0; i < seq.size(); ++i) bytes[i] = seq[i]->bytes;
+    return (int)seq.size();
+}
+
+// the same per kernel class of the train step (indices as ssie_plan_profile_step)
+extern "C" int ssie_plan_class_bytes(void* h, double* bytes)
+{
+    Plan* pl = (Plan*)h;
+    if (!pl || !pl->bound || !bytes) return SSIE_E_ARG;
+    for (int k = 0; k < K_NKINDS; ++k) bytes[k] = 0.0;
+    for (auto* l : {&pl->fwd, &pl->pass2, &pl->lossbwd}) for (auto& f : *l) bytes[f.kind] += f.bytes;
+    return 0;
 }
 
 // number of launches in the three op lists (enhance forward, second decomposition pass, loss + backward)

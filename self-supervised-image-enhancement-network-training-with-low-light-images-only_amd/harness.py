@@ -152,6 +152,40 @@ def draw_crops(n_cubes, shapes, batch_id, batch_size, patch, rng=np.random):
     return out
 
 
+def resolve_dp_mode(dp_mode: str, batch_size: int, world: int) -> str:
+    """"shard": ONE global batch of `batch_size` patches, drawn identically on every rank (same seed), each rank taking its
+    contiguous slice - bit-comparable with a single-GPU run at the same batch_size, needs batch_size % world == 0.
+    "per_rank" (SURVEY 8(e)): `batch_size` patches PER RANK from the rank's own RNG stream (seed + rank), global batch =
+    batch_size x world - what lets the reference's batch 1-2 configurations use 8 GPUs.  "auto" = shard when it divides, else
+    per_rank."""
+    if dp_mode not in ("auto", "shard", "per_rank"):
+        raise ValueError(f"dp_mode must be auto, shard or per_rank, got {dp_mode!r}")
+    if world <= 1:
+        return "shard"
+    if dp_mode == "auto":
+        return "shard" if batch_size % world == 0 else "per_rank"
+    if dp_mode == "shard" and batch_size % world:
+        raise ValueError("dp_mode=shard: batch_size must be divisible by the number of ranks (or use dp_mode=per_rank)")
+    return dp_mode
+
+
+def batches_per_epoch(n_cubes: int, batch_size: int, world: int, mode: str) -> int:
+    """model.py:292: len(train) // batch_size; per_rank mode consumes batch_size x world samples per step (at least one step)"""
+    if mode == "per_rank" and world > 1:
+        return max(1, n_cubes // (batch_size * world))
+    return n_cubes // batch_size
+
+
+def rank_crops(n_cubes, shapes, batch_id, batch_size, patch, rank, world, mode, rng):
+    """this rank's (cube index, x0, y0, mode) records of global step `batch_id`.
+    shard: the reference's draw for the whole batch (model.py:304-308) on the shared stream, then this rank's slice;
+    per_rank: the rank's own stream, sample i of the rank being sample (batch_id * world + rank) * batch_size + i of the epoch."""
+    if mode == "per_rank" and world > 1:
+        return draw_crops(n_cubes, shapes, batch_id * world + rank, batch_size, patch, rng)
+    crops = draw_crops(n_cubes, shapes, batch_id, batch_size, patch, rng)
+    return [crops[i] for i in dp.shard_range(batch_size, rank, world)]
+
+
 class LaggedScalars:
     """Loss read-back that does not stall the launch loop (SURVEY §8(f) N1 "async loss logging"; the reference blocks on seven
     `.item()` calls per step, model.py:566-574).  After every step the 7 device scalars are copied into a slot of a pinned ring
@@ -192,8 +226,10 @@ class LaggedScalars:
 
 
 def train_model(net, train_data_path, eval_data_path, batch_size, patch_size, num_epochs, ckpt_dir, eval_result_dir,
-                eval_every_epoch, label_dir, mat_key="data", normalization="global_normalization", log=print):
-    """model.py:236-341 on the device.  Returns the per-epoch mean losses."""
+                eval_every_epoch, label_dir, mat_key="data", normalization="global_normalization", log=print,
+                dp_mode="auto", seed=41):
+    """model.py:236-341 on the device.  Returns the checkpoint directory.  Multi-GPU (one process per GPU): see resolve_dp_mode;
+    rank 0 logs the losses of ITS shard (every loss is a batch mean, so they estimate the same quantity)."""
     rank, world, _ = dp.init_from_env()
     dev = next(net.parameters()).device
     ckpt_dir = os.path.join(ckpt_dir, "Decomposition_" + str(net.time_stamp))
@@ -208,15 +244,17 @@ def train_model(net, train_data_path, eval_data_path, batch_size, patch_size, nu
         raise ValueError(f"no .mat files under {train_data_path}")
     cubes = _to_device_cubes(train_np, dev)                    # resident in HBM for the whole run
     shapes = [c.shape for c in train_np]
-    if batch_size % world:
-        raise ValueError("batch_size must be divisible by the number of ranks")
-    num_batches = len(train_np) // batch_size
-    mine = dp.shard_range(batch_size, rank, world)
+    mode = resolve_dp_mode(dp_mode, batch_size, world)
+    num_batches = batches_per_epoch(len(train_np), batch_size, world, mode)
+    per_rank = batch_size if mode == "per_rank" else len(dp.shard_range(batch_size, rank, world))
+    # shard: the process-global numpy stream main.py seeded identically on every rank (the reference's own draws);
+    # per_rank: this rank's own stream (seed + rank)
+    rng = np.random.RandomState(dp.rank_seed(seed, rank)) if mode == "per_rank" and world > 1 else np.random
     dp.broadcast_flat_(net.flat_parameters(), world)
     # no per-step host<->device synchronisation: crop records go up through a pinned two-slot ring (slot i is reused at step
     # i + 2, after the lagged read-back below has waited for step i), loss scalars come back one step late
     lag = LaggedScalars(2)
-    nrec = max(len(mine), 1) * ctypes_sizeof_crop()
+    nrec = max(per_rank, 1) * ctypes_sizeof_crop()
     staging = [torch.empty(nrec, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
     step_no = 0
     for epoch in range(num_epochs):
@@ -233,8 +271,8 @@ def train_model(net, train_data_path, eval_data_path, batch_size, patch_size, nu
                     log(f"Epoch [{ep + 1}/{num_epochs}] Batch [{bb + 1}/{num_batches}] Loss: {vals[0]:.6f}")
 
         for b in range(num_batches):
-            crops = draw_crops(len(cubes), shapes, b, batch_size, patch_size)       # same draws on every rank (same seed)
-            x = H.assemble_batch(cubes, [crops[i] for i in mine], patch_size, net.input_channels, staging=staging[step_no & 1])
+            crops = rank_crops(len(cubes), shapes, b, batch_size, patch_size, rank, world, mode, rng)
+            x = H.assemble_batch(cubes, crops, patch_size, net.input_channels, staging=staging[step_no & 1])
             step_no += 1
             scal = net.train_step(x, world)
             consume(lag.push(scal, (epoch, b)))

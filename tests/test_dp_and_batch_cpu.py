@@ -159,3 +159,60 @@ def test_augmentation_index_map_matches_reference(golden_dir):
                 assert L.ssie_aug_source_index(int(mode), P, i, j, ctypes.byref(si), ctypes.byref(sj)) == 0
                 out[i, j] = cube[x0 + si.value, y0 + sj.value]
         assert np.array_equal(out, ref), mode
+
+
+def _crop_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import ssie
+    ssie.load()
+    from ssie_amd import dp, harness
+    r, w, _ = dp.init_from_env("gloo")
+    shapes = [(40, 36, 5), (33, 48, 5), (64, 64, 5)]
+    res = {}
+    for mode_req, bs in (("shard", 4), ("per_rank", 1), ("auto", 1), ("auto", 4)):
+        mode = harness.resolve_dp_mode(mode_req, bs, w)
+        np.random.seed(41)                                             # what main.py does on every rank
+        rng = np.random.RandomState(dp.rank_seed(41, r)) if mode == "per_rank" else np.random
+        steps = [harness.rank_crops(len(shapes), shapes, b, bs, 16, r, w, mode, rng) for b in range(3)]
+        res[(mode_req, bs)] = (mode, steps, harness.batches_per_epoch(len(shapes), bs, w, mode))
+    gathered = [None] * w
+    torch.distributed.all_gather_object(gathered, res)
+    if r == 0:
+        torch.save(gathered, os.path.join(out_dir, "crops.pt"))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_harness_crop_streams_two_ranks(tmp_path):
+    """harness data parallelism as SURVEY 8(e) wrote it, over gloo at world 2 (product functions resolve_dp_mode / rank_crops):
+    shard mode = the single-process draw (model.py:304-308) cut into contiguous rank slices; per_rank mode = every rank its own
+    RNG stream (seed + rank) and its own batch_size samples, cube indices continuing across ranks; auto picks per_rank exactly
+    when the reference's batch size does not divide by the rank count."""
+    import ssie
+    ssie.load()
+    from ssie_amd import dp, harness
+    port = _free_port()
+    mp.spawn(_crop_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g = torch.load(os.path.join(tmp_path, "crops.pt"), weights_only=False)        # written by this test a moment ago
+    shapes = [(40, 36, 5), (33, 48, 5), (64, 64, 5)]
+    # shard, batch 4: concatenating the ranks' slices gives the one-process batch, step by step, on the same stream
+    np.random.seed(41)
+    for b in range(3):
+        whole = harness.draw_crops(3, shapes, b, 4, 16)
+        assert g[0][("shard", 4)][1][b] + g[1][("shard", 4)][1][b] == whole
+    assert g[0][("shard", 4)][0] == "shard" and g[0][("auto", 4)][0] == "shard" and g[0][("auto", 4)][1] == g[0][("shard", 4)][1]
+    assert g[0][("shard", 4)][2] == 0 and g[0][("per_rank", 1)][2] == 1          # 3 cubes: 3 // 4 batches; 3 // (1 * 2) steps
+    # per_rank, batch 1 (the reference's own batch size on 2 GPUs): own streams, consecutive cube indices
+    for r in range(2):
+        mode, steps, _ = g[r][("per_rank", 1)]
+        assert mode == "per_rank" and g[r][("auto", 1)][0] == "per_rank" and g[r][("auto", 1)][1] == steps
+        rng = np.random.RandomState(dp.rank_seed(41, r))
+        for b, crops in enumerate(steps):
+            assert crops == harness.draw_crops(3, shapes, b * 2 + r, 1, 16, rng)
+            assert [c[0] for c in crops] == [(b * 2 + r) % 3]
+    assert g[0][("per_rank", 1)][1] != g[1][("per_rank", 1)][1]
+    with pytest.raises(ValueError):
+        harness.resolve_dp_mode("shard", 1, 2)
+    assert harness.resolve_dp_mode("per_rank", 3, 1) == "shard"                   # one process: nothing to choose

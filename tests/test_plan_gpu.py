@@ -200,6 +200,13 @@ def test_side_stream_overlap_is_bit_identical(pkg):
     assert torch.equal(out[0][1], out[1][1])
 
 
+# Full small gradients vs the reference's fp32 values: two independent fp32 evaluations, each with its own sg() flips.  At 64 bands on
+# 32 x 32 planes the REFERENCE's own fp32 gradients sit up to 8.9e-3 (conv3.0.bias; shallow_conv.0.bias 4.1e-3) from the fp64 oracle
+# (at 31 bands: 1.8e-4) - measured in the build container - so that case gets 2e-2; the noise-free pins of the same launches are the
+# b64_64 / b64_128 injected chains (tests/test_backward_gpu.py, fixed 2e-5).
+GOLDEN_GRAD_TOL = {"b64_32": 2e-2}
+
+
 @pytest.mark.parametrize("case", ["b5_16", "b31_32", "b31_64", "b64_32"])
 def test_golden_reference_outputs(pkg, golden_dir, case):
     """HIP path vs the reference's own outputs (fixtures made by tests/golden/make_golden.py)."""
@@ -230,7 +237,7 @@ def test_golden_reference_outputs(pkg, golden_dir, case):
         assert abs(gr.double().norm().item() - ref_norm) <= 5e-3 * ref_norm + 1e-12, name
         if "grad/" + name in g.files:
             r = torch.from_numpy(g["grad/" + name]).reshape(-1)
-            assert rel_l2(gr.cpu(), r) <= 6e-3, name
+            assert rel_l2(gr.cpu(), r) <= GOLDEN_GRAD_TOL.get(case, 6e-3), name
 
 
 @pytest.mark.parametrize("fused_tail", [1, 0])
