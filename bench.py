@@ -73,7 +73,13 @@ def host_threads():
     return max(1, min(ncpu, int(os.environ.get("SSIE_CPU_THREADS", "16"))))
 
 
-WINO_EXECUTED = 16.0 / 36.0      # multiplications of F(2x2,3x3) per direct 3x3 multiplication
+WINO_EXECUTED = 16.0 / 36.0      # multiplications of F(2x2,3x3) (and of the F(3x3,2x2) weight gradient) per direct 3x3 multiplication
+WINO4_EXECUTED = 36.0 / 144.0    # ... of F(4x4,3x3)
+
+
+def executed_fraction(kernel_class):
+    """share of a class's direct-convolution FLOPs that its MFMAs execute"""
+    return WINO4_EXECUTED if "F(4x4" in kernel_class else WINO_EXECUTED if "winograd" in kernel_class else 1.0
 
 
 def dominant_traffic(kernel_substr, workload):
@@ -104,7 +110,7 @@ def class_table(agg, reps, class_bytes=None):
         e = {"ms_per_step": round(ms, 3), "launches": cnt,
              "tflops": round(fl / (ms * 1e-3) / 1e12, 2) if fl > 0 and ms > 0 else None}
         if "winograd" in k and fl > 0 and ms > 0:       # "tflops" = direct-convolution FLOPs / time; the MFMAs execute 16/36 of them
-            e["executed_mfma_tflops"] = round(fl * WINO_EXECUTED / (ms * 1e-3) / 1e12, 2)
+            e["executed_mfma_tflops"] = round(fl * executed_fraction(k) / (ms * 1e-3) / 1e12, 2)
         b = (class_bytes or {}).get(k, 0.0)
         if b > 0 and ms > 0:
             e["algorithmic_GBps"] = round(b / (ms * 1e-3) / 1e9, 1)
@@ -232,10 +238,10 @@ def run_train(args, torch, dist, hostlib, model, world, rank, dev):
         ms, fl, cnt = agg[dom]
         # a Winograd F(2x2,3x3) launch executes 16/36 of the direct convolution's multiplications: the MFMA roofline is priced on
         # the EXECUTED FLOPs, the direct-convolution figure is reported beside it
-        executed = WINO_EXECUTED if "winograd" in dom else 1.0
+        executed = executed_fraction(dom)
         ach = fl * executed / (ms * 1e-3) / 1e12
         sub = ("conv_wgrad_kernel" if "wgrad" in dom else "conv_wgrad_wino_kernel" if "winograd" in dom and "weight" in dom
-               else "conv_wino_kernel" if "winograd" in dom
+               else "conv_wino4_kernel" if "F(4x4" in dom else "conv_wino_kernel" if "winograd" in dom
                else "conv_fprop_v2w_kernel" if bands <= 64 else "conv_fprop_v2")
         traffic, tk, tsrc = dominant_traffic(sub, args.workload)
         out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
@@ -357,16 +363,16 @@ def run_infer(args, torch, hostlib, model, dev):
                 a = agg.setdefault(k, [0.0, 0.0, 0]); a[0] += ms[i]; a[1] += fl[i]; a[2] += 1
         dom = max(agg, key=lambda k: agg[k][0])
         dms, dfl, dcnt = agg[dom]
-        executed = WINO_EXECUTED if "winograd" in dom else 1.0   # the MFMA roofline is priced on EXECUTED FLOPs (see run_train)
+        executed = executed_fraction(dom)   # the MFMA roofline is priced on EXECUTED FLOPs (see run_train)
         ach = dfl * executed / (dms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
         alg_bytes = infer_algorithmic_bytes(hw, bands, bf16)
         # MFMA floor of the whole forward on the FLOPs its kernels execute: Winograd launches 16/36 of their direct-convolution
         # count; the frequency-domain 9x9 is HBM-bound and left out of the MFMA floor
-        exec_gflop = sum(v[1] * (WINO_EXECUTED if "winograd" in k else 0.0 if "spectral" in k else 1.0) for k, v in agg.items()) / reps / 1e9
+        exec_gflop = sum(v[1] * (0.0 if "spectral" in k else executed_fraction(k)) for k, v in agg.items()) / reps / 1e9
         t_mfma = exec_gflop / 1e3 / peak * 1e3                  # ms
         t_hbm = alg_bytes / (PEAK_HBM_TBS * 1e12) * 1e3
-        traffic, tk, tsrc = dominant_traffic("conv_fprop_bf16" if bf16 else "conv_wino_kernel" if "winograd" in dom else "conv_fprop_v2", args.workload)
+        traffic, tk, tsrc = dominant_traffic("conv_fprop_bf16" if bf16 else "conv_wino4_kernel" if "F(4x4" in dom else "conv_wino_kernel" if "winograd" in dom else "conv_fprop_v2", args.workload)
         # algorithmic HBM bytes per launch from the plan's own op list (operands read once, results written once at storage precision)
         ob = (C.c_double * cap)()
         L.ssie_plan_op_bytes.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int]

@@ -162,11 +162,11 @@ int ssie_selfsup_loss_fwd_bwd(const float* x, int x_cs, const float* RL, int rl_
                               void* ws, size_t ws_bytes, void* stream);
 
 /* one compute_loss+backward with a HIP event after every launch: device milliseconds, algorithmic FLOPs and
- * launch counts per kernel class (synchronises; used by bench.py's roofline leg).  Arrays have 13 entries:
+ * launch counts per kernel class (synchronises; used by bench.py's roofline leg).  Arrays have 14 entries:
  * {conv_fprop<64>, conv_fprop<32>, conv_wgrad, wgrad_reduce, colsum, pack, loss, fft_loss, attention, elementwise,
- *  spectral 9x9 conv, Winograd 3x3 conv, Winograd 3x3 weight gradient}.  The last three are counted with the FLOPs of the direct
- * convolution they replace. */
-#define SSIE_NKINDS 13
+ *  spectral 9x9 conv, Winograd F(2x2,3x3) conv, Winograd 3x3 weight gradient, Winograd F(4x4,3x3) conv}.  The last four are counted
+ * with the FLOPs of the direct convolution they replace (the matrix pipe executes 16/36, 16/36 and 36/144 of them). */
+#define SSIE_NKINDS 14
 int ssie_plan_profile_step(void* plan, const float* x, const long* strides4, void* stream,
                            double* ms, double* flops, int* counts);
 

@@ -763,9 +763,51 @@ __device__ __forceinline__ void ssie_pack_wino_one(const PackDesc& d, long idx)
     }
 }
 
+// Winograd F(4x4, 3x3) weights (conv_wino4.hip): one thread = one (8-channel step, channel pair g, n) -> the 36 transform positions
+// U = G g G^T of both channels, written in the LDS image of a K step: dst[step][n / 32][xi][(n % 32) / 16][g][n % 16][2]
+__device__ __forceinline__ void ssie_pack_wino4_one(const PackDesc& d, long idx)
+{
+    const long total = (long)d.nchunks * 4 * d.Npad;
+    if (idx >= total) return;
+    const int n = (int)(idx % d.Npad); long r = idx / d.Npad;
+    const int g = (int)(r & 3); const int step = (int)(r >> 2);
+    const int kb = step * 8 + 2 * g;
+    float w9[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int ts = (int)d.tapsel[t] * d.s_t;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int k = kb + s;
+            const float wv = d.w[(long)min(n, d.N - 1) * d.s_n + (long)min(k, d.K - 1) * d.s_k + ts];
+            w9[t][s] = (k < d.K && n < d.N) ? wv : 0.f;
+        }
+    }
+    const float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                           {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+    float2* dst = (float2*)d.dst + ((size_t)(step * (d.Npad / 32) + n / 32) * 36) * 128 + (((n % 32) / 16) * 4 + g) * 16 + (n % 16);
+    float m[6][3][2];      // G g
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) m[i][s][e] = G[i][0] * w9[0 * 3 + s][e] + G[i][1] * w9[1 * 3 + s][e] + G[i][2] * w9[2 * 3 + s][e];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float2 u;
+            u.x = m[i][0][0] * G[j][0] + m[i][1][0] * G[j][1] + m[i][2][0] * G[j][2];
+            u.y = m[i][0][1] * G[j][0] + m[i][1][1] * G[j][1] + m[i][2][1] * G[j][2];
+            dst[(size_t)(i * 6 + j) * 128] = u;
+        }
+}
+
 __global__ void pack_weights_kernel(const PackDesc d)
 {
-    if (d.wino) ssie_pack_wino_one(d, (long)blockIdx.x * blockDim.x + threadIdx.x);
+    if (d.wino == 2) ssie_pack_wino4_one(d, (long)blockIdx.x * blockDim.x + threadIdx.x);
+    else if (d.wino) ssie_pack_wino_one(d, (long)blockIdx.x * blockDim.x + threadIdx.x);
     else ssie_pack_one(d, (long)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
@@ -775,8 +817,9 @@ __global__ void pack_weights_batched_kernel(const PackDesc* __restrict__ descs)
     const PackDesc& d = descs[blockIdx.y];
     if (d.wino) {
         const long total = (long)d.nchunks * 4 * d.Npad;
-        for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x)
-            ssie_pack_wino_one(d, idx);
+        for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+            if (d.wino == 2) ssie_pack_wino4_one(d, idx); else ssie_pack_wino_one(d, idx);
+        }
         return;
     }
     long total4 = (long)d.nchunks * d.T * 4 * d.Npad;
@@ -825,6 +868,7 @@ static int ssie_launch_fprop_nt1(const ConvParams& p, hipStream_t st)
 
 int ssie_launch_fprop(const ConvParams& p, hipStream_t st)
 {
+    if (p.wino == 2) return ssie_launch_fprop_wino4(p, st);
     if (p.wino) return ssie_launch_fprop_wino(p, st);
     if (p.tconv) return ssie_launch_tconv(p, st);
     if (ssie_fprop_use_v2 && ssie_fprop_v2_ok(p)) return ssie_launch_fprop_v2(p, st);

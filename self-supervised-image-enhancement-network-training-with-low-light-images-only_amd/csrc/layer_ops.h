@@ -20,9 +20,9 @@ SrcDesc ssie_make_src(const float* ptr, int C, int cstride, int coff, int Hs, in
 size_t ssie_packed_floats(int K, int N, int T);
 PackDesc ssie_make_pack(const float* w, float* dst, int K, int N, const TapList& t, int s_k, int s_n, int s_t);
 size_t ssie_wino_packed_floats(int K, int N);
-bool ssie_wino_eligible(const ConvParams& p, const TapList& t);
-PackDesc ssie_make_pack_wino(const float* w, float* dst, int K, int N, const TapList& t, int s_k, int s_n, int s_t);
-void ssie_conv_to_wino(ConvParams& p, const float* u);
+int ssie_wino_eligible(const ConvParams& p, const TapList& t);     // 0 = no, 1 = F(2x2,3x3) (conv_wino.hip), 2 = F(4x4,3x3) (conv_wino4.hip)
+PackDesc ssie_make_pack_wino(const float* w, float* dst, int K, int N, const TapList& t, int s_k, int s_n, int s_t, int kind);
+void ssie_conv_to_wino(ConvParams& p, const float* u, int kind);
 PackDesc ssie_make_pack_bf16(const float* w, float* dst, int K, int N, const TapList& t, int s_k, int s_n, int s_t);
 int ssie_make_conv(ConvParams& p, const SrcDesc* srcs, int nsrc, int N, int Hv, int Wv, const TapList& t, int si,
                    int Ho, int Wo, const float* wpacked, int Cout,

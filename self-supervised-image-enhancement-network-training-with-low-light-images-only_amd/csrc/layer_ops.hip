@@ -206,10 +206,17 @@ int ssie_fprop_wino_min_tiles = 256;  // ... when the launch has at least this m
 extern "C" void ssie_debug_set_wino(int v) { ssie_fprop_wino = v; }
 extern "C" void ssie_debug_set_wino_min_tiles(int v) { ssie_fprop_wino_min_tiles = v; }
 
+int ssie_fprop_wino4 = 1;             // A/B switch: 1 = eligible launches run the F(4x4, 3x3) kernel (conv_wino4.hip) instead of F(2x2, 3x3)
+int ssie_fprop_wino4_min_tiles = 256; // ... when the launch has at least this many 16 x 64 x 32-channel tiles (tests set 1)
+extern "C" void ssie_debug_set_wino4(int v) { ssie_fprop_wino4 = v; }
+extern "C" void ssie_debug_set_wino4_min_tiles(int v) { ssie_fprop_wino4_min_tiles = v; }
+
+// room for either Winograd form: F(2x2,3x3) = 16 transform positions in 16-channel chunks, F(4x4,3x3) = 36 in 8-channel steps
 size_t ssie_wino_packed_floats(int K, int N)
 {
     const int npad = N > 32 ? ssie_round_up(N, 64) : 32;
-    return (size_t)ssie_ceil_div(K, SSIE_CK) * 16 * 16 * npad;
+    const size_t f2 = (size_t)ssie_ceil_div(K, SSIE_CK) * 16 * 16 * npad, f4 = (size_t)ssie_ceil_div(K, 8) * 36 * 8 * npad;
+    return f2 > f4 ? f2 : f4;
 }
 
 // a full 3 x 3 tap list with offsets in [-1, 1]^2 (forward or flipped data-gradient order)
@@ -224,29 +231,41 @@ static bool taps_are_3x3(const TapList& t)
     return seen == 0x1ff;
 }
 
-// would conv_wino_kernel take this launch?  (geometry from ssie_make_conv, its tap list)
-bool ssie_wino_eligible(const ConvParams& p, const TapList& t)
+// would a Winograd kernel take this launch?  (geometry from ssie_make_conv, its tap list)  0 = no, 1 = conv_wino_kernel F(2x2,3x3),
+// 2 = conv_wino4_kernel F(4x4,3x3): sources at the launch's own resolution (no up-sampling on read), at most a quarter of the 64-wide
+// tile columns wasted, slot offsets inside the DMA table's 24 bits, and enough 16 x 64 tiles to fill the chip
+int ssie_wino_eligible(const ConvParams& p, const TapList& t)
 {
-    if (!ssie_fprop_wino || !taps_are_3x3(t) || p.si != 1 || p.so != 1 || p.py || p.px) return false;
-    if (p.Ho != p.Hv || p.Wo != p.Wv || p.Hout != p.Ho || p.Wout != p.Wo) return false;
+    if (!taps_are_3x3(t) || p.si != 1 || p.so != 1 || p.py || p.px) return 0;
+    if (p.Ho != p.Hv || p.Wo != p.Wv || p.Hout != p.Ho || p.Wout != p.Wo) return 0;
+    if (ssie_fprop_wino4) {
+        bool ok = ssie_round_up(p.Wo, 64) * 3 <= p.Wo * 4;
+        for (int s = 0; s < p.nsrc && ok; ++s)
+            ok = p.src[s].sy == 1.f && p.src[s].sx == 1.f && p.src[s].Hs == p.Hv && p.src[s].Ws == p.Wv &&
+                 (size_t)(18 * p.Wv + 66) * p.src[s].cstride * 4 < (1u << 24) && (size_t)p.Hv * p.Wv * p.src[s].cstride * 4 < (1u << 31);
+        const long tiles4 = (long)p.N * ssie_ceil_div(p.Ho, 16) * ssie_ceil_div(p.Wo, 64) * (p.Cout_pad / 32);
+        if (ok && tiles4 >= ssie_fprop_wino4_min_tiles) return 2;
+    }
+    if (!ssie_fprop_wino) return 0;
     const long tiles = (long)p.N * ssie_ceil_div(p.Ho, 16) * ssie_ceil_div(p.Wo, 32) * (p.Cout_pad / 32);
-    return tiles >= ssie_fprop_wino_min_tiles;
+    return tiles >= ssie_fprop_wino_min_tiles ? 1 : 0;
 }
 
-PackDesc ssie_make_pack_wino(const float* w, float* dst, int K, int N, const TapList& t, int s_k, int s_n, int s_t)
+PackDesc ssie_make_pack_wino(const float* w, float* dst, int K, int N, const TapList& t, int s_k, int s_n, int s_t, int kind)
 {
     PackDesc d = ssie_make_pack(w, dst, K, N, t, s_k, s_n, s_t);
-    d.wino = 1;
+    d.wino = kind;
+    if (kind == 2) d.nchunks = ssie_ceil_div(K, 8);
     for (int i = 0; i < 9; ++i) d.tapsel[(t.dy[i] + 1) * 3 + t.dx[i] + 1] = t.sel[i];
     return d;
 }
 
-// re-target a stride-1 3 x 3 geometry at conv_wino_kernel: 16 x 32 tiles, 32-channel blocks, weights = U
-void ssie_conv_to_wino(ConvParams& p, const float* u)
+// re-target a stride-1 3 x 3 geometry at conv_wino_kernel (16 x 32 tiles) / conv_wino4_kernel (16 x 64 tiles): 32-channel blocks, weights = U
+void ssie_conv_to_wino(ConvParams& p, const float* u, int kind)
 {
-    p.wino = 1; p.wpacked = u;
-    p.th = 16; p.tw = 32; p.hp_h = 18; p.hp_w = 34;
-    p.tiles_y = ssie_ceil_div(p.Ho, 16); p.tiles_x = ssie_ceil_div(p.Wo, 32);
+    p.wino = kind; p.wpacked = u;
+    p.th = 16; p.tw = kind == 2 ? 64 : 32; p.hp_h = 18; p.hp_w = p.tw + 2;
+    p.tiles_y = ssie_ceil_div(p.Ho, 16); p.tiles_x = ssie_ceil_div(p.Wo, p.tw);
     p.co_blocks = p.Cout_pad / 32;
 }
 
@@ -370,11 +389,11 @@ extern "C" int ssie_conv2d_fwd(const ssie_src_t* srcs, int nsrc, int N, int Hv, 
     ConvParams p;
     int rc = ssie_make_conv(p, sd, nsrc, N, Hv, Wv, t, stride, Ho, Wo, wp, cout, out, Ho, Wo, out_cstride, out_coff, 1, 0, 0, e);
     if (rc) return rc;
-    const bool wino = ssie_wino_eligible(p, t);
-    PackDesc pd = wino ? ssie_make_pack_wino(weight, wp, cin_w, cout, t, /*s_k*/ T, /*s_n*/ cin_w * T, 1)
+    const int wino = ssie_wino_eligible(p, t);
+    PackDesc pd = wino ? ssie_make_pack_wino(weight, wp, cin_w, cout, t, /*s_k*/ T, /*s_n*/ cin_w * T, 1, wino)
                        : ssie_make_pack(weight, wp, cin_w, cout, t, /*s_k*/ T, /*s_n*/ cin_w * T, 1);
     if (ssie_launch_pack(pd, st)) return SSIE_E_LAUNCH;
-    if (wino) ssie_conv_to_wino(p, wp);
+    if (wino) ssie_conv_to_wino(p, wp, wino);
     if (!(p.tile_counter = take_counters(cur, end, 1, st))) return SSIE_E_WORKSPACE;
     return ssie_launch_fprop(p, st) ? SSIE_E_LAUNCH : 0;
 }
@@ -453,10 +472,10 @@ extern "C" int ssie_conv2d_dgrad(const float* g, int g_cstride, int g_coff, int 
         int rc = ssie_make_conv(p, &in, 1, N, Ho, Wo, t, 1, Hin, Win, wp, cs, gx, Hin, Win, gx_cstride, gx_coff, 1, 0, 0, e);
         if (rc) return rc;
         // OIHW: k = co -> stride cin_total*T, n = ci -> stride T
-        const bool wino = ssie_wino_eligible(p, t);
-        PackDesc pd = wino ? ssie_make_pack_wino(wbase, wp, cout, cs, t, cin_total * T, T, 1) : ssie_make_pack(wbase, wp, cout, cs, t, cin_total * T, T, 1);
+        const int wino = ssie_wino_eligible(p, t);
+        PackDesc pd = wino ? ssie_make_pack_wino(wbase, wp, cout, cs, t, cin_total * T, T, 1, wino) : ssie_make_pack(wbase, wp, cout, cs, t, cin_total * T, T, 1);
         if (ssie_launch_pack(pd, st)) return SSIE_E_LAUNCH;
-        if (wino) ssie_conv_to_wino(p, wp);
+        if (wino) ssie_conv_to_wino(p, wp, wino);
         if (!(p.tile_counter = take_counters(cur, end, 1, st))) return SSIE_E_WORKSPACE;
         return ssie_launch_fprop(p, st) ? SSIE_E_LAUNCH : 0;
     }

@@ -24,7 +24,7 @@ namespace {
 
 typedef std::function<int(hipStream_t)> FnT;
 // op kinds for per-kernel-class profiling (bench.py roofline): see ssie_plan_profile_step
-enum { K_FPROP2 = 0, K_FPROP1, K_WGRAD, K_WGRAD_REDUCE, K_COLSUM, K_PACK, K_LOSS, K_FFT, K_ATTN, K_ELEMENTWISE, K_SPEC, K_WINO, K_WGRAD_WINO, K_NKINDS };
+enum { K_FPROP2 = 0, K_FPROP1, K_WGRAD, K_WGRAD_REDUCE, K_COLSUM, K_PACK, K_LOSS, K_FFT, K_ATTN, K_ELEMENTWISE, K_SPEC, K_WINO, K_WGRAD_WINO, K_WINO4, K_NKINDS };
 // How a launch touches the two weight-gradient slab areas (run_ops_overlapped orders the streams by THIS, never by kind):
 //   SLAB_WRITE  produces partial slabs in area `slab` on the main stream (any weight-gradient kernel)
 //   SLAB_READ   consumes area `slab` on the side stream (slab reduction, Winograd tap extraction - anything reading the area)
@@ -249,7 +249,7 @@ struct Builder {
         // algorithmic FLOPs: real (un-padded) channels and taps only
         const double fl = 2.0 * p.N * p.Ho * p.Wo * (double)p.Cout * k_real * p.ntaps;
         char tag[96];
-        snprintf(tag, sizeof(tag), "%sconv k%d->n%d taps%d si%d so%d %dx%d", p.wino ? "winograd " : p.tconv ? "transposed (4 classes) " : "", k_real, p.Cout, p.ntaps, p.si, p.so, p.Ho, p.Wo);
+        snprintf(tag, sizeof(tag), "%sconv k%d->n%d taps%d si%d so%d %dx%d", p.wino == 2 ? "winograd F(4x4,3x3) " : p.wino ? "winograd " : p.tconv ? "transposed (4 classes) " : "", k_real, p.Cout, p.ntaps, p.si, p.so, p.Ho, p.Wo);
         // algorithmic bytes: each source's physical pixels (an up-sampled source is read at ITS resolution) x the channels taken, the
         // output positions of this launch x real output channels, the fused epilogue operands, the packed weights
         const double ein = h16 ? 2.0 : 4.0, eout = (h16 && p.out_bf16) ? 2.0 : 4.0;
@@ -270,7 +270,7 @@ struct Builder {
             ops.back().bytes = by;
             return;
         }
-        ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_fprop(p, st); }, p.wino ? K_WINO : p.Cout_pad % 64 == 0 ? K_FPROP2 : K_FPROP1, fl, tag));
+        ops.push_back(Fn([p](hipStream_t st) { return ssie_launch_fprop(p, st); }, p.wino == 2 ? K_WINO4 : p.wino ? K_WINO : p.Cout_pad % 64 == 0 ? K_FPROP2 : K_FPROP1, fl, tag));
         ops.back().bytes = by;
     }
     // bf16 list: which outputs stay fp32 (API outputs and the attention operands)
@@ -305,9 +305,9 @@ struct Builder {
         int rc = ssie_make_conv(p, srcs.data(), (int)srcs.size(), pl.N, Hv, Wv, t, stride, Ho, Wo, wp, L.cout,
                                 pl.buf(out), ob.H, ob.W, ob.cs, out_coff, 1, 0, 0, e);
         if (rc) return rc;
-        if (ssie_wino_eligible(p, t)) {
-            pl.packs.push_back(ssie_make_pack_wino(pl.P + L.w, wp, L.cin, L.cout, t, T, L.cin * T, 1));
-            ssie_conv_to_wino(p, wp);
+        if (const int wk = ssie_wino_eligible(p, t)) {
+            pl.packs.push_back(ssie_make_pack_wino(pl.P + L.w, wp, L.cin, L.cout, t, T, L.cin * T, 1, wk));
+            ssie_conv_to_wino(p, wp, wk);
         } else pl.packs.push_back(ssie_make_pack(pl.P + L.w, wp, L.cin, L.cout, t, T, L.cin * T, 1));
         push(ops, p, L.cin);
         return 0;
@@ -375,9 +375,9 @@ struct Builder {
             ConvParams p;
             int rc = ssie_make_conv(p, &in, 1, pl.N, gb.H, gb.W, t, 1, xb.H, xb.W, wp, cs, pl.buf(gx), xb.H, xb.W, xb.cs, 0, 1, 0, 0, e);
             if (rc) return rc;
-            if (ssie_wino_eligible(p, t)) {
-                pl.packs.push_back(ssie_make_pack_wino(wbase, wp, L.cout, cs, t, L.cin * T, T, 1));
-                ssie_conv_to_wino(p, wp);
+            if (const int wk = ssie_wino_eligible(p, t)) {
+                pl.packs.push_back(ssie_make_pack_wino(wbase, wp, L.cout, cs, t, L.cin * T, T, 1, wk));
+                ssie_conv_to_wino(p, wp, wk);
             } else pl.packs.push_back(ssie_make_pack(wbase, wp, L.cout, cs, t, L.cin * T, T, 1));
             push(ops, p, L.cout);
             return 0;

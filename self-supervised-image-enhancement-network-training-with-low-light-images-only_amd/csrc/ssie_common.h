@@ -74,7 +74,7 @@ struct ConvParams {
     int tw;                 // output tile columns: 16, or 32 for the wide v2 kernel (big 64-channel stride-1 3x3 layers)
     int* tile_counter;      // optional dynamic tile queue (device int, zero before the launch); null = static stride
     int out_bf16;           // bf16 inference kernel only: element type of `out` (addsrc / out2 are always bf16 there)
-    int wino;               // 1: geometry and weights (U = G g G^T, 16 transform positions) of conv_wino_kernel (conv_wino.hip)
+    int wino;               // 1: geometry and weights (U = G g G^T, 16 transform positions) of conv_wino_kernel (conv_wino.hip); 2: of conv_wino4_kernel (36 positions)
     int tconv;              // 1: all four output-parity classes of a stride-2 transposed 3 x 3 convolution in one launch (conv_tconv.hip)
     int out2_cstride;       // bf16 inference kernel only: elements per pixel of `out2` when it differs from out_cstride (0 = the same) -
                             // the fp32 R|I output (B + 1 padded to 4) and its bf16 twin (padded to 8) at band counts like 64 or 256
@@ -108,6 +108,7 @@ struct PackDesc {
     int8_t tapsel[SSIE_MAX_TAPS];
     int bf16;               // 1: pack for the bf16 kernel - dst[chunk32][t][slot 0..3][n][8 bf16], k = chunk*32 + 8*slot + s
     int wino;               // 1: Winograd F(2x2,3x3) weights - dst[chunk][xi 0..15][q][n][4] = (G g G^T)[xi], tapsel[r*3+s] = source tap of g[r][s]
+                            // 2: Winograd F(4x4,3x3) weights - dst[step of 8][n / 32][xi 0..35][(n % 32) / 16][pair g][n % 16][2] (conv_wino4.hip)
 };
 
 // host launchers (conv_kernels.hip); return 0 on success
@@ -116,6 +117,7 @@ bool ssie_fprop_v2_ok(const ConvParams& p);            // conv_fprop_v2.hip
 int ssie_launch_fprop_v2(const ConvParams& p, hipStream_t st);
 int ssie_launch_tconv(const ConvParams& p, hipStream_t st);        // conv_tconv.hip; p over ssie_taps_transposed_all
 int ssie_launch_fprop_wino(const ConvParams& p, hipStream_t st);   // conv_wino.hip; p from ssie_conv_to_wino
+int ssie_launch_fprop_wino4(const ConvParams& p, hipStream_t st);  // conv_wino4.hip; p from ssie_conv_to_wino (kind 2)
 int ssie_launch_fprop_bf16(const ConvParams& p, hipStream_t st);   // conv_fprop_bf16.hip; p from ssie_make_conv_bf16
 extern int ssie_fprop_min_tiles16;                     // launches with fewer tiles than this use the 8 x 16 register-staged kernel (layer_ops.hip)
 extern int ssie_fprop_use_v2;                          // tuning / A-B switch (1 = use the 512-thread DMA kernel when eligible)

@@ -347,7 +347,7 @@ class Plan:
 
     KINDS = ("conv_fprop(+dgrad) 64-ch tile", "conv_fprop(+dgrad) 32-ch tile", "conv_wgrad_kernel", "wgrad_reduce_kernel", "colsum",
              "pack_weights", "loss_direct", "fft_loss_kernel", "attention", "elementwise", "spectral 9x9 conv (fwd + dgrad + wgrad)",
-             "winograd 3x3 conv (fwd + dgrad)", "winograd 3x3 weight gradient")
+             "winograd 3x3 conv (fwd + dgrad)", "winograd 3x3 weight gradient", "winograd F(4x4,3x3) conv (fwd + dgrad)")
 
     def profile_step(self, x):
         """{kernel class: (device ms, algorithmic FLOPs, launches)} of one loss+backward step (HIP events)."""

@@ -141,17 +141,20 @@ def check_chain(H, case, n, bands, h, w, coefs, forced=None):
     assert not bad, "backward-chain parity failures:\n" + "\n".join(bad)
 
 
-@pytest.fixture(params=[None, "dma_kernels", "winograd"])
+@pytest.fixture(params=[None, "dma_kernels", "winograd", "winograd4"])
 def forced_kernels(pkg, request):
     """None = launch heuristics (8x16 tiles at these small batches); "dma_kernels" = the kernels the bench-size layers
     run (16x16 / 16x32 DMA tiles, split 32-channel workgroups) forced through the same cases (include/ssie_debug.h);
     "winograd" = the Winograd F(2x2,3x3) kernel for every stride-1 3x3 forward / data-gradient launch."""
     L = pkg.lib()
-    if request.param == "winograd":               # every stride-1 3x3 forward / data-gradient launch on conv_wino8_kernel (F(2x2,3x3))
+    if request.param in ("winograd", "winograd4"):  # every stride-1 3x3 forward / data-gradient launch on conv_wino_kernel (F(2x2,3x3)) -
+        # "winograd4": on conv_wino4_kernel (F(4x4,3x3)) wherever it is eligible (sources at their own resolution, >= 48 columns)
+        L.ssie_debug_set_wino4_min_tiles(1 if request.param == "winograd4" else 1 << 30)
         L.ssie_debug_set_wino_min_tiles(1)
         L.ssie_debug_set_wgrad_wino_min_tiles(1)
         L.ssie_debug_set_tconv_min_tiles(1)       # and the one-launch transposed convolution (conv_tconv.hip)
     elif request.param:
+        L.ssie_debug_set_wino4_min_tiles(1 << 30)
         L.ssie_debug_set_wino_min_tiles(1 << 30)
         L.ssie_debug_set_wgrad_wino_min_tiles(1 << 30)
         L.ssie_debug_set_fprop_min_tiles16(0)
@@ -161,6 +164,7 @@ def forced_kernels(pkg, request):
         L.ssie_debug_set_spectral9(0)             # and the 9 x 9 convolution on the direct MFMA kernels instead of the frequency domain
     yield request.param
     L.ssie_debug_set_tconv_min_tiles(32)
+    L.ssie_debug_set_wino4_min_tiles(256)
     L.ssie_debug_set_wino_min_tiles(256)
     L.ssie_debug_set_wgrad_wino_min_tiles(256)
     L.ssie_debug_set_skinny_final(1)
@@ -172,7 +176,8 @@ def forced_kernels(pkg, request):
 
 @pytest.mark.parametrize("case", list(CASES))
 def test_backward_chain_injected(pkg, case, forced_kernels):
-    if forced_kernels and (case in ("b5_16", "b5_256", "b64_128") or (case == "b256_64" and forced_kernels != "winograd")):
+    if forced_kernels and (case in ("b5_16", "b5_256") or (case == "b64_128" and forced_kernels != "winograd4") or
+                           (case == "b256_64" and forced_kernels not in ("winograd", "winograd4"))):
         pytest.skip("forced-kernel variant runs on the mid-size cases only (time); 256 bands: the Winograd / tconv kernels only")
     n, bands, h, w, coefs = CASES[case]
     check_chain(pkg, case, n, bands, h, w, coefs, forced_kernels)

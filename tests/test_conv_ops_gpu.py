@@ -20,7 +20,7 @@ def H():
     return hostlib
 
 
-@pytest.fixture(autouse=True, params=["heuristic", "tile16x16", "tile16x32", "winograd", "tconv1"])
+@pytest.fixture(autouse=True, params=["heuristic", "tile16x16", "tile16x32", "winograd", "winograd4", "tconv1"])
 def kernel_mode(H, request):
     """The launch heuristics pick 8x16 tiles (register-staged kernel) for launches as small as these tests; the two forced
     modes run the same cases through the DMA kernels the bench-size layers use: 16x16 tiles (conv_fprop_v2_kernel) and
@@ -29,15 +29,19 @@ def kernel_mode(H, request):
     the other three modes keep it off so the direct kernels stay covered.  "tconv1" runs every eligible stride-2 transposed 3x3
     convolution (ConvTranspose2d forward, stride-2 data gradient) on the one-launch kernel (conv_tconv.hip) whatever its size."""
     L = H.lib()
-    L.ssie_debug_set_wino_min_tiles(1 if request.param == "winograd" else 1 << 30)
+    # "winograd4": every eligible stride-1 3x3 forward / data-gradient launch (sources at their own resolution, width >= 48) on
+    # conv_wino4_kernel (F(4x4, 3x3), conv_wino4.hip), the rest on F(2x2, 3x3); "winograd" keeps F(4x4) off so F(2x2) stays covered
+    L.ssie_debug_set_wino4_min_tiles(1 if request.param == "winograd4" else 1 << 30)
+    L.ssie_debug_set_wino_min_tiles(1 if request.param in ("winograd", "winograd4") else 1 << 30)
     L.ssie_debug_set_tconv_min_tiles(1 if request.param == "tconv1" else 1 << 30)
     L.ssie_debug_set_wgrad_wino_min_tiles(1 if request.param == "winograd" else 1 << 30)   # weight gradients: F(3x3,2x2)
-    if request.param not in ("heuristic", "winograd"):
+    if request.param not in ("heuristic", "winograd", "winograd4"):
         L.ssie_debug_set_fprop_min_tiles16(0)
         L.ssie_debug_set_fprop_wide_min_tiles(1 if request.param == "tile16x32" else 1 << 30)
         L.ssie_debug_set_fprop_v2_split_min_tiles(1 if request.param == "tile16x32" else 1 << 30)   # 32-channel layers: two 4-wave workgroups per CU
     yield request.param
     L.ssie_debug_set_tconv_min_tiles(32)
+    L.ssie_debug_set_wino4_min_tiles(256)
     L.ssie_debug_set_wino_min_tiles(256)
     L.ssie_debug_set_wgrad_wino_min_tiles(256)
     L.ssie_debug_set_fprop_min_tiles16(256)
@@ -91,6 +95,12 @@ def close(got, ref, tol=TOL):
     (64, 65, 3, 1, 16, 32, 2),          # recon with 65 outputs (a ragged third 32-channel block), sigmoid,
     (64, 64, 9, 1, 16, 16, 0),          # shallow_conv at 64 input channels
     (64, 32, 3, 1, 18, 22, 1),          # conv0 at 64 bands
+    (64, 64, 3, 1, 20, 64, 1),          # widths the F(4x4, 3x3) kernel takes (>= 48 columns, <= 1/4 of the 64-wide tile wasted):
+    (31, 32, 3, 1, 33, 130, 1),         # ragged rows and columns (3 tile columns, the last one 2 wide), partial channel step (31 = 3 x 8 + 7)
+    (96, 64, 3, 1, 16, 48, 0),          # 12 K steps
+    (128, 128, 3, 1, 32, 64, 1),        # four output-channel blocks
+    (68, 64, 3, 1, 17, 64, 0),          # 65 -> 68 padded channels: the last step holds one channel quad
+    (64, 31, 3, 1, 16, 128, 2),         # ragged output-channel block, sigmoid
 ])
 def test_conv2d_fwd(H, cin, cout, k, stride, h, w, act):
     n = 2
@@ -175,6 +185,10 @@ def _conv_grads(x, wt, stride, g, transposed=False):
     (65, 64, 3, 1, 16, 32),
     (64, 65, 3, 1, 16, 32),
     (64, 64, 9, 1, 16, 16),
+    (64, 64, 3, 1, 20, 64),             # F(4x4, 3x3)-eligible widths (data gradient incl. mask + accumulate, split input channels)
+    (32, 64, 3, 1, 33, 130),
+    (128, 128, 3, 1, 16, 64),
+    (96, 64, 3, 1, 12, 48),
 ])
 def test_conv2d_dgrad_wgrad(H, cin, cout, k, stride, h, w):
     n = 2

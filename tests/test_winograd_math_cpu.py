@@ -47,3 +47,62 @@ def test_dma_slot_decodes():
         assert (x * 3856) >> 16 == x // 17
     for x in range(192):
         assert (x * 3641) >> 16 == x // 18
+
+
+def _bt6(d):
+    """the 1-D input transform of F(4x4, 3x3) exactly as conv_wino4.hip evaluates it (two independent output triples)"""
+    d0, d1, d2, d3, d4, d5 = d
+    r0 = d0 * 4 + (d4 - d2 * 5)
+    s, t = d4 - d2 * 4, d3 - d1 * 4
+    r1, r2 = s + t, s - t
+    s2, t2 = d4 - d2, d3 - d1
+    r3, r4 = t2 * 2 + s2, s2 - t2 * 2
+    r5 = d1 * 4 + (d5 - d3 * 5)
+    return np.array([r0, r1, r2, r3, r4, r5])
+
+
+def _at6(m):
+    """the 1-D output transform of F(4x4, 3x3) as the kernel's epilogue evaluates it"""
+    m0, m1, m2, m3, m4, m5 = m
+    s1, d1, s2, d2 = m1 + m2, m1 - m2, m3 + m4, m3 - m4
+    return np.array([m0 + s1 + s2, d1 + 2 * d2, s1 + 4 * s2, d1 + 8 * d2 + m5])
+
+
+def test_f4x4_3x3_forward_identity_as_coded():
+    """conv_wino4.hip: Y = A^T [(G g G^T) (.) (B^T d B)] A with the matrices of its header, the input transform done horizontally
+    first (rows of the patch) and then vertically, xi = 6 i + j with i the vertical index - against the direct correlation."""
+    BT = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], float)
+    G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], float)
+    AT = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], float)
+    rng = np.random.default_rng(4)
+    for _ in range(10):
+        d = rng.standard_normal((6, 6)); g = rng.standard_normal((3, 3))
+        ref = np.array([[sum(g[r, s] * d[y + r, x + s] for r in range(3) for s in range(3)) for x in range(4)] for y in range(4)])
+        assert np.abs(AT @ ((G @ g @ G.T) * (BT @ d @ BT.T)) @ AT.T - ref).max() < 1e-11
+        rt = np.array([_bt6(d[a]) for a in range(6)])                  # horizontal: rt[a][j]
+        V = np.array([_bt6(rt[:, j]) for j in range(6)]).T             # vertical:   V[i][j]
+        assert np.abs(V - BT @ d @ BT.T).max() < 1e-11
+        M = (G @ g @ G.T) * V
+        t = np.array([_at6(M[:, j]) for j in range(6)]).T              # over i: t[y][j]
+        Y = np.array([_at6(t[y]) for y in range(4)])                   # over j: Y[y][x]
+        assert np.abs(Y - ref).max() < 1e-11
+
+
+def test_f4x4_dma_slot_decode():
+    """conv_wino4.hip's halo layout [half][phase][row][column group]: the slot decode of its DMA table covers every (row, column) of the
+    18 x 66 halo tile exactly once per channel half, and r2 // 17 == (r2 * 3856) >> 16 on its range"""
+    V_PHASE, V_HALF, V_HP = 18 * 17, 4 * 18 * 17, 2 * 4 * 18 * 17
+    seen = set()
+    for sid in range(5 * 512):
+        h = int(sid >= V_HALF); r = sid - h * V_HALF
+        ph = (r >= V_PHASE) + (r >= 2 * V_PHASE) + (r >= 3 * V_PHASE); r2 = r - ph * V_PHASE
+        hy = (r2 * 3856) >> 16
+        if sid < V_HP:
+            assert hy == r2 // 17
+        hx = 4 * (r2 - hy * 17) + ph
+        if sid < V_HP and hx < 66:
+            assert 0 <= hy < 18 and (h, hy, hx) not in seen
+            seen.add((h, hy, hx))
+            # the reader's address of patch element (a, b) of tile (wm, tx): row 4 wm + a, column 4 tx + b
+            assert sid == ((h * 4 + (hx & 3)) * 18 + hy) * 17 + (hx >> 2)
+    assert len(seen) == 2 * 18 * 66
