@@ -19,25 +19,69 @@
 //   * A operand (16 tiles x 4 k): lane l = tile column l % 16, k-group g = l / 16 = channel PAIR g of the step; the lane reads patch
 //     element (a, b) of its tile as ONE 8-byte word = both channels, so every transform instruction is a packed one (v_pk_fma_f32 /
 //     v_pk_add_f32) and the two halves of a result feed the step's two MFMAs of a xi
-//   * halo layout [channel half][column phase = col & 3][halo row][col >> 2] 16-byte slots: the 16 lanes of a k-group read every
-//     fourth column = consecutive slots of one phase plane, the four k-groups the two 8-byte halves of two slot planes: conflict-free
+//   * halo layout [shift group = (col >> 2) & 1][channel half][phase = col & 3][halo row][col >> 3] 16-byte slots, group 1 shifted by
+//     8 bytes: the even / odd tiles of a k-group read the two groups, i.e. disjoint bank pairs: conflict-free 8-byte reads (see V_SHIFT)
 //   * B^T d B in two halves of three output columns each (the 1-D transform's outputs {0,1,2} and {3,4,5} share no subexpression, so
 //     splitting costs no arithmetic): the 6 x 6 patch is read twice per step instead of holding 72 registers of it
 //   * U comes out of the weight-packing launch (PackDesc.wino = 2) in exactly the LDS image of a step: [xi][half][g][channel][2]
 #include "conv_device.h"
 #include <type_traits>
 
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#ifndef SSIE_WINO4_UREG
+#define SSIE_WINO4_UREG 0           // 1: U of the next step through registers instead of LDS-DMA (A/B: slower, see the step body)
+#endif
+#ifndef SSIE_WINO4_DMA_COL
+#define SSIE_WINO4_DMA_COL(w) ((w) >> 1)      // transform column (0 .. 5) behind which wave w issues the next step's DMA
+#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// ablation builds (tools/build_variants.py conv_wino4.hip name=-DSSIE_X4_...): one phase compiled out, results wrong, timing only
+#ifdef SSIE_X4_NOMFMA
+#define MFMA16(a, b, c) ({ f32x4 c_ = (c); asm volatile("" : "+v"(c_) : "v"(a), "v"(b)); c_; })
+#else
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#endif
+
+// Diagnostic build only (-DSSIE_STAMP, tools/stamp_wino4.py): s_memtime of wave SSIE_STAMP_WAVE (default 0) per phase, summed per workgroup:
+// [0] start [1] wait for the step's DMA (vmcnt) [2] wait at the barrier [3] end [4] DMA issue [5] epilogue + tile bookkeeping [6] tiles
+// [7] the rest of the step bodies.  The shipped library never executes a stamp.
+#ifdef SSIE_STAMP
+#ifndef SSIE_STAMP_WAVE
+#define SSIE_STAMP_WAVE 0
+#endif
+__device__ unsigned long long* ssie_stamp_buf_wino4 = nullptr;
+extern "C" int ssie_debug_set_stamp_buffer_wino4(void* buf)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(ssie_stamp_buf_wino4), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+#define ST_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t_ = __builtin_amdgcn_s_memtime(); st_[0] = st_t_;
+#define ST_ACC(k) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_[k] += t_ - st_t_; st_t_ = t_; } while (0)
+#define ST_FLUSH do { st_[3] = __builtin_amdgcn_s_memtime(); if (ssie_stamp_buf_wino4 && threadIdx.x == 64 * SSIE_STAMP_WAVE) \
+    for (int k_ = 0; k_ < 8; ++k_) ssie_stamp_buf_wino4[(size_t)blockIdx.x * 8 + k_] = st_[k_]; } while (0)
+#else
+#define ST_DECL
+#define ST_ACC(k)
+#define ST_FLUSH
+#endif
 
 namespace {
 
 constexpr int V_TH = 16, V_TW = 64, V_HPH = 18, V_HPW = 66, V_CK = 8;
-constexpr int V_IDX = 17;                           // column groups per phase plane (66 columns)
-constexpr int V_PHASE = V_HPH * V_IDX;              // slots per (half, phase) plane: 306
-constexpr int V_HALF = 4 * V_PHASE;                 // 16-byte slots per channel half: 1224
-constexpr int V_HP = 2 * V_HALF;                    // slots per halo buffer: 2448 (the fifth DMA round is masked to them)
-constexpr int V_ROUNDS = (V_HP + 511) / 512;        // 5
+// Halo buffer: 16-byte slots (one pixel, one channel half = two channel pairs) in the order
+//   [shift group sg = (col >> 2) & 1][channel half h][phase ph = col & 3][halo row][column group idx = col >> 3]
+// and group 1 sits 8 BYTES further than its slot index says.  A k-group's 16 lanes read 8 bytes (their channel pair) of 16 slots: the
+// even tiles' columns 8 u + b and the odd tiles' 8 u + 4 + b lie in phases p and p ^ 4, i.e. in the two shift groups, so the even
+// lanes cover banks {4 u, 4 u + 1} and the odd lanes {4 u + 2, 4 u + 3}: conflict-free (unshifted, lanes u and u + 8 of the 16-byte-
+// strided slots share a bank pair: measured SQ_LDS_BANK_CONFLICT = 38 % of the LDS cycles).
+constexpr int V_IDX = 9;                            // column groups per phase plane (66 columns = 8.25 groups of 8)
+constexpr int V_PLANE = V_HPH * V_IDX;              // slots per (group, half, phase) plane: 162
+constexpr int V_HSL = 4 * V_PLANE;                  // per (group, half): 648
+constexpr int V_SG = (2 * V_HSL + 63) / 64 * 64;    // slots per shift group, whole DMA pieces: 1344 (1296 used)
+constexpr int V_SLOTS = 2 * V_SG;                   // 2688
+constexpr int V_PIECES = V_SLOTS / 64;              // 42 DMA pieces of 64 slots
+constexpr int V_ROUNDS = (V_PIECES + 7) / 8;        // 6 (the last one: pieces 40, 41)
+constexpr int V_HP = V_SLOTS + 1;                   // float4 per halo buffer incl. the 8-byte shift (rounded to 16)
+constexpr int V_SHIFT = V_SG * 16 + 8;              // byte distance group 0 -> group 1 of the same (h, ph, row, idx)
 constexpr int V_BSZ = 36 * 2 * 4 * 16 * 2 / 4;      // float4 per U step: 2304 (36 KB)
 constexpr int V_UPIECES = V_BSZ / 64;               // 36 DMA pieces of 1 KB
 
@@ -47,72 +91,72 @@ constexpr int V_UPIECES = V_BSZ / 64;               // 36 DMA pieces of 1 KB
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // a * k + c and c - a * k, k a uniform constant pair
-__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 k, f32x2 c) { f32x2 r; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(k), "v"(c)); return r; }
-__device__ __forceinline__ f32x2 pk_fnma(f32x2 a, f32x2 k, f32x2 c) { f32x2 r; asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(k), "v"(c)); return r; }
+// (k lives in an SGPR pair: one constant-bus operand per instruction is allowed, and it costs no vector register)
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 k, f32x2 c) { f32x2 r; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(c)); return r; }
+__device__ __forceinline__ f32x2 pk_fnma(f32x2 a, f32x2 k, f32x2 c) { f32x2 r; asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "s"(k), "v"(c)); return r; }
 #define V4_FENCE6(a, b, c, d, e, f) asm volatile("s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f))
 
-// 16 outputs of one lane = the 4 x 4 pixels of one tile, one channel: k = 4 y + x
-#define V4_EOFF(k) ((long)((k) >> 2) * rowstride + (long)((k) & 3) * pixstride)
+// one output row of a tile pair = 2 x 4 consecutive pixels of one channel: v[0..3] tile A, v[4..7] tile B (4 * pixstride further... the
+// tiles are neighbours: 8 consecutive pixels).  Fused operands are loaded for all 8 elements before use.
 template <typename PT>
-__device__ __forceinline__ void wino4_epilogue16(const PT& p, float v[16], size_t o0, long rowstride, long pixstride, float bv)
+__device__ __forceinline__ void wino4_epilogue8(const PT& p, float v[8], size_t o0, long pixstride, float bv)
 {
     if (p.act == ACT_RELU) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = fmaxf(v[k] + bv, 0.f);
+        for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] + bv, 0.f);
     } else if (p.act == ACT_SIGMOID) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = 1.f / (1.f + expf(-(v[k] + bv)));
+        for (int k = 0; k < 8; ++k) v[k] = 1.f / (1.f + expf(-(v[k] + bv)));
     } else {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] += bv;
+        for (int k = 0; k < 8; ++k) v[k] += bv;
     }
     if (p.mask_mode != MASK_NONE) {
         const float* mp = p.mask_y + o0;
-        float y[16];
+        float y[8];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) y[k] = mp[V4_EOFF(k)];
+        for (int k = 0; k < 8; ++k) y[k] = mp[k * pixstride];
         if (p.mask_mode == MASK_RELU) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = y[k] > 0.f ? v[k] : 0.f;
+            for (int k = 0; k < 8; ++k) v[k] = y[k] > 0.f ? v[k] : 0.f;
         } else {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] *= y[k] * (1.f - y[k]);
+            for (int k = 0; k < 8; ++k) v[k] *= y[k] * (1.f - y[k]);
         }
     }
     if (p.out2) {
         float* o2 = p.out2 + o0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) o2[V4_EOFF(k)] = v[k];
+        for (int k = 0; k < 8; ++k) o2[k * pixstride] = v[k];
     }
     if (p.addsrc) {
         const float* ap = p.addsrc + o0;
-        float a[16];
+        float a[8];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) a[k] = ap[V4_EOFF(k)];
+        for (int k = 0; k < 8; ++k) a[k] = ap[k * pixstride];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] += a[k];
+        for (int k = 0; k < 8; ++k) v[k] += a[k];
     }
     float* ob = p.out + o0;
     if (p.accumulate) {
-        float a[16];
+        float a[8];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) a[k] = ob[V4_EOFF(k)];
+        for (int k = 0; k < 8; ++k) a[k] = ob[k * pixstride];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] += a[k];
+        for (int k = 0; k < 8; ++k) v[k] += a[k];
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) ob[V4_EOFF(k)] = v[k];
+    for (int k = 0; k < 8; ++k) ob[k * pixstride] = v[k];
 }
 
 template <typename PT>
-__device__ __forceinline__ void wino4_epilogue16_ragged(const PT& p, const float v[16], size_t o0, long rowstride, long pixstride, float bv,
-                                                         int oy, int ox)
+__device__ __forceinline__ void wino4_epilogue8_ragged(const PT& p, const float v[8], size_t o0, long pixstride, float bv, int oy, int ox)
 {
+    if (oy >= p.Hout) return;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int y = oy + (k >> 2), x = ox + (k & 3);
-        if (y >= p.Hout || x >= p.Wout) continue;
-        const size_t o = o0 + V4_EOFF(k);
+    for (int k = 0; k < 8; ++k) {
+        if (ox + k >= p.Wout) continue;
+        const size_t o = o0 + k * pixstride;
         float t = v[k] + bv;
         if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
         else if (p.act == ACT_SIGMOID) t = 1.f / (1.f + expf(-t));
@@ -131,20 +175,21 @@ template <bool SINGLE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino4_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    constexpr int NTHR = 512;
     f32x4* As0 = (f32x4*)smem_f;                    // [2][V_HP]
     f32x4* Bs0 = As0 + 2 * V_HP;                    // [2][V_BSZ]
     int* s_next = (int*)(Bs0 + 2 * V_BSZ);
-    int* dma_tab = s_next + 16;                     // [V_ROUNDS][NTHR]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, nh = wave >> 2;        // tile row of the workgroup tile, 16-channel half of the 32-channel block
     const int g = lane >> 4, tx = lane & 15;
-    // this lane's patch: halo rows 4 wm + a, halo columns 4 tx + b -> phase b & 3, column group tx + (b >> 2); channel pair g lives in
-    // the 8-byte half g & 1 of slot plane g >> 1
-    const int abase = ((((g >> 1) * 4) * V_HPH + 4 * wm) * V_IDX + tx) * 16 + (g & 1) * 8;
-#define V4_AOFF(a, b) (((((b) & 3) * V_HPH + (a)) * V_IDX + ((b) >> 2)) * 16)
+    // this lane's patch: halo rows 4 wm + a, halo columns 4 tx + b = 8 u + 4 e + b (tx = 2 u + e).  Element (a, b) of an even tile sits at
+    // V4_AOFF(a, b) from abase0 / abase1 (b < 4 / b >= 4); an odd tile's column is 4 further: the OTHER shift group, and for b >= 4 the
+    // next column group - folded into the two per-lane bases, so every element stays a compile-time offset
+    const int u8 = tx >> 1, e8 = tx & 1;
+    const int acommon = ((((g >> 1) * 4) * V_HPH + 4 * wm) * V_IDX + u8) * 16 + (g & 1) * 8;
+    const int abase0 = acommon + e8 * V_SHIFT, abase1 = acommon + e8 * (16 - V_SHIFT);
+#define V4_AOFF(a, b) (((b) >> 2) * V_SHIFT + ((((b) & 3) * V_HPH + (a)) * V_IDX) * 16)
     const int bbase = ((nh * 4 + g) * 16 + tx) * 8;           // U[xi][nh][g][tx][2 channels]; + xi * 1024 bytes
     const int nsteps = (p.Cin + V_CK - 1) / V_CK;
     const int total_tiles = p.N * p.tiles_y * p.tiles_x * p.co_blocks;
@@ -156,37 +201,48 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         B0_ = (q_ % p.tiles_x) * V_TW; q_ /= p.tiles_x;                                   \
         A0_ = (q_ % p.tiles_y) * V_TH; N_ = q_ / p.tiles_y;                               \
     }
-    // Per-lane DMA table (conv_wino.hip): for each of the lane's 5 halo slots the byte offset of its source relative to the tile origin
-    // (24 bits; sources of one channel stride) | halo column << 24 (7 bits) | channel half << 31.  [different strides: pixel offset]
+    // Per-lane DMA table, kept in REGISTERS (the LDS has no room for it): for each of the lane's 6 halo slots (slot i * 512 + tid) the byte
+    // offset of its source relative to the tile origin (24 bits; sources of one channel stride) | halo column << 24 (7 bits) | channel
+    // half << 31; 0xffffffff = a padding slot of the layout (fetches nothing).  [sources of different strides: pixel offset]
     const int cs_common = SINGLE ? p.src[0].cstride
                                  : ((p.nsrc < 2 || p.src[1].cstride == p.src[0].cstride) && (p.nsrc < 3 || p.src[2].cstride == p.src[0].cstride)
                                     ? p.src[0].cstride : 0);
+    unsigned te[V_ROUNDS];
 #pragma unroll
     for (int i = 0; i < V_ROUNDS; ++i) {
-        const int id = i * NTHR + tid;
-        const int h = id >= V_HALF, r = id - h * V_HALF;
-        const int ph = (r >= V_PHASE) + (r >= 2 * V_PHASE) + (r >= 3 * V_PHASE), r2 = r - ph * V_PHASE;
-        const int hy = (r2 * 3856) >> 16;                       // r2 / 17 for r2 < 384
-        const int hx = 4 * (r2 - hy * V_IDX) + ph;
-        const bool real = id < V_HP && hx < V_HPW;
+        const int id = i * 512 + tid;
+        const int sg = id >= V_SG, r = id - sg * V_SG;
+        const int h = r >= V_HSL, r1 = r - h * V_HSL;
+        const int ph = (r1 >= V_PLANE) + (r1 >= 2 * V_PLANE) + (r1 >= 3 * V_PLANE), r2 = r1 - ph * V_PLANE;
+        const int hy = (r2 * 7282) >> 16;                       // r2 / 9 for r2 < 256
+        const int hx = 8 * (r2 - hy * V_IDX) + 4 * sg + ph;
+        const bool real = id < V_SLOTS && r < 2 * V_HSL && hx < V_HPW;
         const int pix = hy * p.Wv + hx;
         const int lo = cs_common ? (pix * cs_common + 4 * h) * 4 : pix;
-        dma_tab[i * NTHR + tid] = real ? (int)((unsigned)lo | ((unsigned)hx << 24) | ((unsigned)h << 31)) : 0;
+        te[i] = real ? ((unsigned)lo | ((unsigned)hx << 24) | ((unsigned)h << 31)) : 0xffffffffu;
     }
 #define V4_RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, (int)(bytes), 0x00020000)
 #define V4_BLDS(rs, lptr, vo, so) __builtin_amdgcn_raw_ptr_buffer_load_lds((rs), (__attribute__((address_space(3))) void*)(lptr), 16, (int)(vo), (int)(so), 0, 0)
-    // DMA of one K step: U = 36 pieces of 1 KB (wave w: pieces w, w + 8, ...), halo = 5 rounds of 512 slots
-#define V4_PREFETCH(STEP, N_, A0_, B0_, CB_, BUF)                                                             \
+    // Operands of one K step.  Halo: LDS-DMA, 42 pieces of 64 slots (wave w: pieces w, w + 8, ...; pieces 21 .. 41 = shift group 1 land 8
+    // bytes further); padding slots fetch an out-of-range offset (zeros, never read).  U (36 pieces of 1 KB, wave w: pieces w, w + 8, ...)
+    // goes THROUGH REGISTERS - an ordinary buffer load per piece, written to LDS one transform column later: the CU's LDS-DMA path
+    // moves about 20 bytes per clock (stamped: ~400 cycles of issue stall per 1 KB piece with 78 pieces per step in flight), and
+    // 74 KB per 8-channel step was more than it carries in a step's time; ordinary loads have their own, wider path.
+#define V4_URSRC(STEP, CB_) V4_RSRC((const f32x4*)p.wpacked + ((size_t)(STEP) * p.co_blocks + (CB_)) * V_BSZ, V_BSZ * 16)
+#define V4_PREFETCH_U(STEP, CB_, BUF)          /* first step of the kernel only: U by LDS-DMA like the halo */    \
     {                                                                                                         \
         f32x4* bbuf_ = Bs0 + (BUF) * V_BSZ;                                                                   \
-        const __amdgpu_buffer_rsrc_t ur_ = V4_RSRC((const f32x4*)p.wpacked + ((size_t)(STEP) * p.co_blocks + (CB_)) * V_BSZ, V_BSZ * 16); \
+        const __amdgpu_buffer_rsrc_t ur_ = V4_URSRC(STEP, CB_);                                               \
         _Pragma("unroll") for (int q_ = 0; q_ < (V_UPIECES + 7) / 8; ++q_) {                                  \
             const int pc_ = q_ * 8 + wave;                                                                    \
             if (pc_ < V_UPIECES) V4_BLDS(ur_, bbuf_ + pc_ * 64, lane * 16, pc_ * 1024);                       \
         }                                                                                                     \
+    }
+#define V4_PREFETCH(STEP, N_, A0_, B0_, CB_, BUF)                                                             \
+    {                                                                                                         \
         const SrcSel s_ = SINGLE ? ssie_only_src(p) : ssie_pick_src(p, (STEP) * V_CK);                        \
         const int vy0_ = (A0_) - 1, vx0_ = (B0_) - 1;                                                         \
-        f32x4* abuf_ = As0 + (BUF) * V_HP;                                                                    \
+        char* abuf_ = (char*)(As0 + (BUF) * V_HP);                                                            \
         const int c0_ = (STEP) * V_CK - s_.cbeg;                                                              \
         /* one resource per (source, image): rows outside the image are out-of-range offsets -> zeros */      \
         const __amdgpu_buffer_rsrc_t ar_ = V4_RSRC(s_.ptr + (size_t)(N_) * p.Hv * p.Wv * s_.cstride,          \
@@ -195,20 +251,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const unsigned xlo_ = max(0, -vx0_), xn_ = min(V_HPW, p.Wv - vx0_) - xlo_;                            \
         const int jn_ = (s_.C - c0_ + 3) >> 2;                                                                \
         const unsigned cs4_ = (unsigned)s_.cstride * 4u;                                                      \
-        unsigned te_[V_ROUNDS];                                                                               \
-        _Pragma("unroll") for (int i_ = 0; i_ < V_ROUNDS; ++i_) te_[i_] = (unsigned)dma_tab[i_ * NTHR + tid]; \
-        if (xn_ == (unsigned)V_HPW && jn_ >= 2) {          /* no column outside the image, full channel step */ \
-            _Pragma("unroll") for (int i_ = 0; i_ < V_ROUNDS; ++i_) {                                         \
-                const unsigned lo_ = te_[i_] & 0xffffffu;                                                     \
-                const unsigned off_ = (unsigned)tb_ + (cs_common ? lo_ : __umul24(lo_, cs4_) + ((te_[i_] >> 31) << 4)); \
-                if (i_ < V_ROUNDS - 1 || tid < V_HP - (V_ROUNDS - 1) * NTHR) V4_BLDS(ar_, abuf_ + i_ * NTHR + wave * 64, off_, 0); \
-            }                                                                                                 \
-        } else {                                                                                              \
-            _Pragma("unroll") for (int i_ = 0; i_ < V_ROUNDS; ++i_) {                                         \
-                const unsigned e_ = te_[i_], lo_ = e_ & 0xffffffu, hx_ = (e_ >> 24) & 127, j_ = e_ >> 31;     \
-                const bool ok_ = hx_ - xlo_ < xn_ && (int)j_ < jn_;                                           \
+        const bool inner_ = xn_ == (unsigned)V_HPW && jn_ >= 2;   /* no column outside the image, full channel step */ \
+        _Pragma("unroll") for (int i_ = 0; i_ < V_ROUNDS; ++i_) {                                             \
+            const int pc_ = i_ * 8 + wave;                                                                    \
+            if (pc_ < V_PIECES) {                                                                             \
+                const unsigned e_ = te[i_], lo_ = e_ & 0xffffffu, hx_ = (e_ >> 24) & 127, j_ = e_ >> 31;      \
+                const bool ok_ = e_ != 0xffffffffu && (inner_ || (hx_ - xlo_ < xn_ && (int)j_ < jn_));        \
                 const unsigned off_ = (unsigned)tb_ + (cs_common ? lo_ : __umul24(lo_, cs4_) + (j_ << 4));    \
-                if (i_ < V_ROUNDS - 1 || tid < V_HP - (V_ROUNDS - 1) * NTHR) V4_BLDS(ar_, abuf_ + i_ * NTHR + wave * 64, ok_ ? off_ : 0x80000000u, 0); \
+                V4_BLDS(ar_, abuf_ + pc_ * 1024 + (pc_ >= V_PIECES / 2 ? 8 : 0), ok_ ? off_ : 0x80000000u, 0); \
             }                                                                                                 \
         }                                                                                                     \
     }
@@ -218,10 +268,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int n, a0, b0, cb;
     V4_DECODE(tile, n, a0, b0, cb)
     int gstep = 0;
-    __syncthreads();                                // the DMA table is complete before anyone reads it
+    V4_PREFETCH_U(0, cb, 0)
     V4_PREFETCH(0, n, a0, b0, cb, 0)
     int fetched = 0x7fffffff;
-    const f32x2 k2 = {2.f, 2.f}, k4 = {4.f, 4.f}, k5 = {5.f, 5.f};
+    ST_DECL
+    const f32x2 k2 = {2.f, 2.f}, k4 = {4.f, 4.f}, k5 = {5.f, 5.f}, k8 = {8.f, 8.f};
 
     while (tile < total_tiles) {
         f32x4 acc[36];
@@ -239,13 +290,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     if (step == 0) *s_next = p.tile_counter ? (int)gridDim.x + atomicAdd(p.tile_counter, 1) : tile + (int)gridDim.x;
                 } else if (step == 1) *s_next = fetched;
             }
+            ST_ACC(5);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ST_ACC(1);
             __syncthreads();
+            ST_ACC(2);
             if (step == (nsteps > 1 ? 1 : 0)) {
                 ntile = *s_next;
                 if (ntile < total_tiles) V4_DECODE(ntile, nn, na0, nb0, ncb)
             }
-            const char* Ab = (const char*)(As0 + buf * V_HP) + abase;
+            // what the next step is: the next 8 channels of this tile, or step 0 of the next tile
+            const bool more = step + 1 < nsteps, have_next = more || ntile < total_tiles;
+            const int ps = more ? step + 1 : 0, pn = more ? n : nn, pa0 = more ? a0 : na0, pb0 = more ? b0 : nb0, pcb = more ? cb : ncb;
+#if SSIE_WINO4_UREG
+            const __amdgpu_buffer_rsrc_t unext = V4_URSRC(ps, pcb);
+            f32x4* const ubuf_next = Bs0 + (buf ^ 1) * V_BSZ;
+            u32x4 ureg = {0u, 0u, 0u, 0u};
+#endif
+            const char* Ab0 = (const char*)(As0 + buf * V_HP) + abase0;
+            const char* Ab1 = (const char*)(As0 + buf * V_HP) + abase1;
             const char* Bl = (const char*)(Bs0 + buf * V_BSZ) + bbase;
 #pragma unroll
             for (int H = 0; H < 2; ++H) {
@@ -255,7 +318,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int a = 0; a < 6; ++a) {
                     f32x2 d[6];
 #pragma unroll
-                    for (int b = 0; b < 6; ++b) d[b] = *(const f32x2*)(Ab + V4_AOFF(a, b));
+                    for (int b = 0; b < 6; ++b) d[b] = *(const f32x2*)((b < 4 ? Ab0 : Ab1) + V4_AOFF(a, b));
+#ifdef SSIE_X4_NOXFORM
+                    rt[a][0] = d[0 + 3 * H]; rt[a][1] = d[1 + 3 * H]; rt[a][2] = d[2 + 3 * H];
+#else
                     if (H == 0) {
                         rt[a][0] = pk_fma(d[0], k4, pk_fnma(d[2], k5, d[4]));
                         const f32x2 s = pk_fnma(d[2], k4, d[4]), t = pk_fnma(d[1], k4, d[3]);
@@ -265,11 +331,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         rt[a][0] = pk_fma(t, k2, s); rt[a][1] = pk_fnma(t, k2, s);
                         rt[a][2] = pk_fma(d[1], k4, pk_fnma(d[3], k5, d[5]));
                     }
+#endif
                 }
 #pragma unroll
                 for (int bq = 0; bq < 3; ++bq) {
                     // vertical transform of column 3 H + bq -> the six xi = 6 i + 3 H + bq
                     f32x2 v[6];
+#ifdef SSIE_X4_NOXFORM
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) v[i] = rt[i][bq];
+#else
                     {
                         const f32x2 d0 = rt[0][bq], d1 = rt[1][bq], d2 = rt[2][bq], d3 = rt[3][bq], d4 = rt[4][bq], d5 = rt[5][bq];
                         v[0] = pk_fma(d0, k4, pk_fnma(d2, k5, d4));
@@ -279,6 +350,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         v[3] = pk_fma(t2, k2, s2); v[4] = pk_fnma(t2, k2, s2);
                         v[5] = pk_fma(d1, k4, pk_fnma(d3, k5, d5));
                     }
+#endif
                     f32x2 bf[6];
 #pragma unroll
                     for (int i = 0; i < 6; ++i) bf[i] = *(const f32x2*)(Bl + (i * 6 + 3 * H + bq) * 1024);
@@ -293,51 +365,85 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         const int xi = i * 6 + 3 * H + bq;
                         acc[xi] = MFMA16(v[i].y, bf[i].y, acc[xi]);
                     }
-                    // the next step's DMA goes out behind the first column's MFMAs (waves 0-3) / the second column's (waves 4-7, their SIMD
-                    // partners: a wave sits at DMA issue while its previous pieces are in flight, so partners must not do it together)
-                    if (H == 0 && bq == (wave >= 4 ? 1 : 0)) {
-                        if (step + 1 < nsteps) V4_PREFETCH(step + 1, n, a0, b0, cb, buf ^ 1)
-                        else if (ntile < total_tiles) V4_PREFETCH(0, nn, na0, nb0, ncb, buf ^ 1)
+#ifndef SSIE_X4_NODMA
+#if SSIE_WINO4_UREG
+                    // (measured slower, 219 -> 236 us on 64 -> 64 at 128 x 128: vmcnt retires in order, so an ordinary load queued behind
+                    // the halo's LDS-DMA pieces is waited for as long as they are)  the next step's U through registers, one piece per column
+                    if (have_next) {
+                        const int col = 3 * H + bq;
+                        if (col >= 1 && (col - 1) * 8 + wave < V_UPIECES) *(u32x4*)(ubuf_next + ((col - 1) * 8 + wave) * 64 + lane) = ureg;
+                        if (col <= 4 && col * 8 + wave < V_UPIECES) ureg = __builtin_amdgcn_raw_buffer_load_b128(unext, lane * 16, (col * 8 + wave) * 1024, 0);
                     }
+#endif
+                    // The next step's DMA.  The CU's LDS-DMA path takes a 1 KB piece about every 50 cycles and a wave sits at issue until its
+                    // pieces are accepted: waves that issue TOGETHER each wait for all of their pieces (stamped: 2 600 - 4 300 cycles per step
+                    // with four waves at a time), so every wave pair gets its own transform column - waves 2 c, 2 c + 1 behind column c -
+                    // which also keeps SIMD partners (w, w + 4) two columns apart
+                    if (3 * H + bq == SSIE_WINO4_DMA_COL(wave)) {
+                        ST_ACC(7);
+                        if (have_next) {
+#if !SSIE_WINO4_UREG
+                            V4_PREFETCH_U(ps, pcb, buf ^ 1)
+#endif
+                            V4_PREFETCH(ps, pn, pa0, pb0, pcb, buf ^ 1)
+                        }
+                        ST_ACC(4);
+                    }
+#endif
                 }
             }
             if (tid == 0 && step == 0 && nsteps > 1 && p.tile_counter)
                 fetched = (int)gridDim.x + atomicAdd(p.tile_counter, 1);
+            ST_ACC(7);
         };
         step_body(std::true_type{}, 0); ++gstep;
         for (int step = 1; step < nsteps; ++step, ++gstep) step_body(std::false_type{}, step);
 
-        // output transform (lane-local: register r of all 36 accumulators = tile column 4 g + r, channel co) + epilogue
+        // output transform (lane-local: register r of all 36 accumulators = tile column 4 g + r, channel co), packed over register pairs
+        // (r, r + 1) = two tiles, + epilogue
+#ifdef SSIE_X4_NOEPI
+        if (co < p.Cout && acc[0][0] == 123.456f) {
+#else
         if (co < p.Cout) {
-            const long rowstride = (long)p.Wout * p.out_cstride, pixstride = p.out_cstride;
+#endif
+            const long pixstride = p.out_cstride;
             const bool full = a0 + V_TH <= p.Hout && b0 + V_TW <= p.Wout;
             const int oy0 = a0 + 4 * wm;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float t[4][6];
+            for (int rp = 0; rp < 2; ++rp) {
+                f32x2 t[4][6];
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
-                    const float m0 = acc[0 * 6 + j][r], m1 = acc[1 * 6 + j][r], m2 = acc[2 * 6 + j][r], m3 = acc[3 * 6 + j][r],
-                                m4 = acc[4 * 6 + j][r], m5 = acc[5 * 6 + j][r];
-                    const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
-                    t[0][j] = m0 + s1 + s2; t[1][j] = d1 + 2.f * d2; t[2][j] = s1 + 4.f * s2; t[3][j] = d1 + 8.f * d2 + m5;
+                    f32x2 m[6];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) m[i] = f32x2{acc[i * 6 + j][2 * rp], acc[i * 6 + j][2 * rp + 1]};
+                    const f32x2 s1 = pk_add(m[1], m[2]), d1 = pk_sub(m[1], m[2]), s2 = pk_add(m[3], m[4]), d2 = pk_sub(m[3], m[4]);
+                    t[0][j] = pk_add(pk_add(m[0], s1), s2); t[1][j] = pk_fma(d2, k2, d1);
+                    t[2][j] = pk_fma(s2, k4, s1); t[3][j] = pk_add(pk_fma(d2, k8, d1), m[5]);
                 }
-                float y[16];
+                // one output row at a time: 8 consecutive pixels (tile 4 g + 2 rp and its right neighbour), this lane's channel
+                const int ox0 = b0 + 4 * (4 * g + 2 * rp);
 #pragma unroll
                 for (int yy = 0; yy < 4; ++yy) {
-                    const float s1 = t[yy][1] + t[yy][2], d1 = t[yy][1] - t[yy][2], s2 = t[yy][3] + t[yy][4], d2 = t[yy][3] - t[yy][4];
-                    y[4 * yy + 0] = t[yy][0] + s1 + s2; y[4 * yy + 1] = d1 + 2.f * d2;
-                    y[4 * yy + 2] = s1 + 4.f * s2; y[4 * yy + 3] = d1 + 8.f * d2 + t[yy][5];
+                    const f32x2 s1 = pk_add(t[yy][1], t[yy][2]), d1 = pk_sub(t[yy][1], t[yy][2]), s2 = pk_add(t[yy][3], t[yy][4]), d2 = pk_sub(t[yy][3], t[yy][4]);
+                    const f32x2 y0 = pk_add(pk_add(t[yy][0], s1), s2), y1 = pk_fma(d2, k2, d1), y2 = pk_fma(s2, k4, s1), y3 = pk_add(pk_fma(d2, k8, d1), t[yy][5]);
+                    float yv[8] = {y0.x, y1.x, y2.x, y3.x, y0.y, y1.y, y2.y, y3.y};
+                    const size_t o0 = ((size_t)(n * p.Hout + oy0 + yy) * p.Wout + ox0) * p.out_cstride + p.out_coff + co;
+                    if (full) wino4_epilogue8(p, yv, o0, pixstride, bv);
+                    else wino4_epilogue8_ragged(p, yv, o0, pixstride, bv, oy0 + yy, ox0);
                 }
-                const int ox0 = b0 + 4 * (4 * g + r);
-                const size_t o0 = ((size_t)(n * p.Hout + oy0) * p.Wout + ox0) * p.out_cstride + p.out_coff + co;
-                if (full) wino4_epilogue16(p, y, o0, rowstride, pixstride, bv);
-                else wino4_epilogue16_ragged(p, y, o0, rowstride, pixstride, bv, oy0, ox0);
             }
         }
         n = nn; a0 = na0; b0 = nb0; cb = ncb; tile = ntile;
+#ifdef SSIE_STAMP
+        st_[6] += 1;
+#endif
     }
+    ST_ACC(5);
+    ST_FLUSH;
 #undef V4_PREFETCH
+#undef V4_PREFETCH_U
+#undef V4_URSRC
 #undef V4_DECODE
 #undef V4_RSRC
 #undef V4_BLDS
@@ -347,7 +453,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 template __global__ void conv_wino4_kernel<false>(const ConvParams);
 template __global__ void conv_wino4_kernel<true>(const ConvParams);
 
-size_t ssie_wino4_lds_bytes() { return (size_t)(2 * V_HP + 2 * V_BSZ) * 16 + 64 + (size_t)V_ROUNDS * 512 * 4; }
+size_t ssie_wino4_lds_bytes() { return (size_t)(2 * V_HP + 2 * V_BSZ) * 16 + 64; }
 
 // p from ssie_conv_to_wino4 (layer_ops.hip: ssie_wino4_eligible has checked sources, sizes and the 24-bit slot offsets)
 int ssie_launch_fprop_wino4(const ConvParams& p, hipStream_t st)

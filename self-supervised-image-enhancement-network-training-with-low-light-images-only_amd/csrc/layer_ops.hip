@@ -207,9 +207,12 @@ extern "C" void ssie_debug_set_wino(int v) { ssie_fprop_wino = v; }
 extern "C" void ssie_debug_set_wino_min_tiles(int v) { ssie_fprop_wino_min_tiles = v; }
 
 int ssie_fprop_wino4 = 1;             // A/B switch: 1 = eligible launches run the F(4x4, 3x3) kernel (conv_wino4.hip) instead of F(2x2, 3x3)
-int ssie_fprop_wino4_min_tiles = 256; // ... when the launch has at least this many 16 x 64 x 32-channel tiles (tests set 1)
+#ifndef SSIE_WINO4_MIN_TILES
+#define SSIE_WINO4_MIN_TILES (1 << 30)      /* off until it beats F(2x2,3x3) on the bench layers: tests and tools force it */
+#endif
+int ssie_fprop_wino4_min_tiles = SSIE_WINO4_MIN_TILES;   // ... when the launch has at least this many 16 x 64 x 32-channel tiles (tests set 1)
 extern "C" void ssie_debug_set_wino4(int v) { ssie_fprop_wino4 = v; }
-extern "C" void ssie_debug_set_wino4_min_tiles(int v) { ssie_fprop_wino4_min_tiles = v; }
+extern "C" void ssie_debug_set_wino4_min_tiles(int v) { ssie_fprop_wino4_min_tiles = v < 0 ? SSIE_WINO4_MIN_TILES : v; }   // v < 0: the default
 
 // room for either Winograd form: F(2x2,3x3) = 16 transform positions in 16-channel chunks, F(4x4,3x3) = 36 in 8-channel steps
 size_t ssie_wino_packed_floats(int K, int N)

@@ -89,20 +89,39 @@ def test_f4x4_3x3_forward_identity_as_coded():
 
 
 def test_f4x4_dma_slot_decode():
-    """conv_wino4.hip's halo layout [half][phase][row][column group]: the slot decode of its DMA table covers every (row, column) of the
-    18 x 66 halo tile exactly once per channel half, and r2 // 17 == (r2 * 3856) >> 16 on its range"""
-    V_PHASE, V_HALF, V_HP = 18 * 17, 4 * 18 * 17, 2 * 4 * 18 * 17
-    seen = set()
-    for sid in range(5 * 512):
-        h = int(sid >= V_HALF); r = sid - h * V_HALF
-        ph = (r >= V_PHASE) + (r >= 2 * V_PHASE) + (r >= 3 * V_PHASE); r2 = r - ph * V_PHASE
-        hy = (r2 * 3856) >> 16
-        if sid < V_HP:
-            assert hy == r2 // 17
-        hx = 4 * (r2 - hy * 17) + ph
-        if sid < V_HP and hx < 66:
-            assert 0 <= hy < 18 and (h, hy, hx) not in seen
-            seen.add((h, hy, hx))
-            # the reader's address of patch element (a, b) of tile (wm, tx): row 4 wm + a, column 4 tx + b
-            assert sid == ((h * 4 + (hx & 3)) * 18 + hy) * 17 + (hx >> 2)
-    assert len(seen) == 2 * 18 * 66
+    """conv_wino4.hip's halo layout [shift group (col >> 2) & 1][half][phase col & 3][row][col >> 3], group 1 shifted by 8 bytes: the
+    slot decode of its DMA table covers every (row, column) of the 18 x 66 halo tile exactly once per channel half; the reader's
+    address of patch element (a, b) of tile (wm, tx) - two per-lane bases + one compile-time offset - is that slot; and the 16 lanes of a
+    k-group hit 16 different 8-byte bank pairs for every (a, b) (r2 // 9 == (r2 * 7282) >> 16 on its range)."""
+    V_HPH, V_IDX = 18, 9
+    V_PLANE = V_HPH * V_IDX; V_HSL = 4 * V_PLANE; V_SG = (2 * V_HSL + 63) // 64 * 64; V_SLOTS = 2 * V_SG; V_SHIFT = V_SG * 16 + 8
+    assert (V_PLANE, V_HSL, V_SG, V_SLOTS) == (162, 648, 1344, 2688)
+    byte_of = {}
+    for sid in range(6 * 512):
+        sg = int(sid >= V_SG); r = sid - sg * V_SG
+        h = int(r >= V_HSL); r1 = r - h * V_HSL
+        ph = (r1 >= V_PLANE) + (r1 >= 2 * V_PLANE) + (r1 >= 3 * V_PLANE); r2 = r1 - ph * V_PLANE
+        hy = (r2 * 7282) >> 16
+        if r2 < V_PLANE:
+            assert hy == r2 // 9
+        hx = 8 * (r2 - hy * V_IDX) + 4 * sg + ph
+        real = sid < V_SLOTS and r < 2 * V_HSL and hx < 66
+        if real:
+            assert 0 <= hy < 18 and (h, hy, hx) not in byte_of
+            piece = sid // 64
+            byte_of[(h, hy, hx)] = piece * 1024 + (8 if piece >= 21 else 0) + (sid % 64) * 16      # where the DMA puts the slot
+    assert len(byte_of) == 2 * 18 * 66
+    aoff = lambda a, b: (b >> 2) * V_SHIFT + (((b & 3) * V_HPH + a) * V_IDX) * 16
+    for wm in range(4):
+        for g in range(4):
+            for a in range(6):
+                for b in range(6):
+                    banks = set()
+                    for tx in range(16):
+                        u, e = tx >> 1, tx & 1
+                        acommon = ((((g >> 1) * 4) * V_HPH + 4 * wm) * V_IDX + u) * 16 + (g & 1) * 8
+                        base = acommon + e * V_SHIFT if b < 4 else acommon + e * (16 - V_SHIFT)
+                        addr = base + aoff(a, b)
+                        assert addr == byte_of[(g >> 1, 4 * wm + a, 4 * tx + b)] + (g & 1) * 8, (wm, g, a, b, tx)
+                        banks.add((addr // 8) % 16)
+                    assert len(banks) == 16, (wm, g, a, b)

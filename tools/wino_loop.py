@@ -11,6 +11,7 @@ cin, cout, hw, N, reps = (int(a) for a in (sys.argv[1:6] if len(sys.argv) > 5 el
 L = H.lib()
 L.ssie_debug_set_wino(int(os.environ.get("WINO", "1")))
 L.ssie_debug_set_wino_min_tiles(1)
+L.ssie_debug_set_wino4_min_tiles(1 if os.environ.get("WINO4", "0") == "1" else 1 << 30)     # WINO4=1: the F(4x4,3x3) kernel
 dev = "cuda"
 x = torch.randn(N, hw, hw, cin, device=dev); w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05; b = torch.randn(cout, device=dev)
 o = torch.zeros(N, hw, hw, cout, device=dev)
