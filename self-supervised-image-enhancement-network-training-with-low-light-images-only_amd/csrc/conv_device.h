@@ -82,6 +82,35 @@ __device__ __forceinline__ void ssie_epilogue_full(const PT& p, const f32x16& ac
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = acc[r] + bv;
     }
+    if (p.out2_mode) {
+        // backward forms (ConvParams.out2_mode; no activation, no skip add): one launch writes a gradient AND its masked copy
+        const float* mp = p.mask_y + o0;
+        float y[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[r] = mp[SSIE_EOFF(r)];
+        float* ob = p.out + o0; float* o2 = p.out2 + o0;
+        if (p.accumulate) {
+            float a[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] = ob[SSIE_EOFF(r)];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += a[r];
+        }
+        float m[16];
+        if (p.mask_mode == MASK_RELU) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m[r] = y[r] > 0.f ? v[r] : 0.f;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m[r] = v[r] * (y[r] * (1.f - y[r]));
+        }
+        // mode 1: out = mask * v, out2 = v;  mode 2: out = total, out2 = mask * total
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ob[SSIE_EOFF(r)] = p.out2_mode == 1 ? m[r] : v[r];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o2[SSIE_EOFF(r)] = p.out2_mode == 1 ? v[r] : m[r];
+        return;
+    }
     if (p.mask_mode != MASK_NONE) {
         const float* mp = p.mask_y + o0;
         float y[16];
@@ -120,6 +149,28 @@ __device__ __forceinline__ void ssie_epilogue_full(const PT& p, const f32x16& ac
     for (int r = 0; r < 16; ++r) ob[SSIE_EOFF(r)] = v[r];
 }
 
+// one output element through the whole fused epilogue (edge tiles, element by element): v = accumulator + bias
+template <typename PT>
+__device__ __forceinline__ void ssie_epilogue_elem(const PT& p, size_t o, float v)
+{
+    if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+    else if (p.act == ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+    if (p.out2_mode) {                       // backward forms, see ssie_epilogue_full
+        const float y = p.mask_y[o];
+        if (p.accumulate) v += p.out[o];
+        const float m = p.mask_mode == MASK_RELU ? (y > 0.f ? v : 0.f) : v * (y * (1.f - y));
+        p.out[o] = p.out2_mode == 1 ? m : v;
+        p.out2[o] = p.out2_mode == 1 ? v : m;
+        return;
+    }
+    if (p.mask_mode == MASK_RELU) v = p.mask_y[o] > 0.f ? v : 0.f;
+    else if (p.mask_mode == MASK_SIGMOID) { float y = p.mask_y[o]; v *= y * (1.f - y); }
+    if (p.out2) p.out2[o] = v;
+    if (p.addsrc) v += p.addsrc[o];
+    if (p.accumulate) v += p.out[o];
+    p.out[o] = v;
+}
+
 // General (edge-tile) variant of the above: per-element bounds checks; arow / bcol = output-grid position of tile
 // element (row 0, column 4h).
 template <typename PT>
@@ -133,15 +184,7 @@ __device__ __forceinline__ void ssie_epilogue_ragged(const PT& p, const f32x16& 
         if (a >= p.Ho || b >= p.Wo) continue;
         if (a * p.so + p.py >= p.Hout || b * p.so + p.px >= p.Wout) continue;
         const size_t o = o0 + tr * rowstride + tc * pixstride;
-        float v = acc[r] + bv;
-        if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-        else if (p.act == ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
-        if (p.mask_mode == MASK_RELU) v = p.mask_y[o] > 0.f ? v : 0.f;
-        else if (p.mask_mode == MASK_SIGMOID) { float y = p.mask_y[o]; v *= y * (1.f - y); }
-        if (p.out2) p.out2[o] = v;
-        if (p.addsrc) v += p.addsrc[o];
-        if (p.accumulate) v += p.out[o];
-        p.out[o] = v;
+        ssie_epilogue_elem(p, o, acc[r] + bv);
     }
 }
 

@@ -253,15 +253,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fprop_v2_kernel(const ConvPar
                     if (a >= p.Ho || b >= p.Wo) continue;
                     if (a * p.so + p.py >= p.Hout || b * p.so + p.px >= p.Wout) continue;
                     const size_t o = o0 + tr * rowstride + tc * pixstride;
-                    float v = acc[m][r] + bv;
-                    if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (p.act == ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
-                    if (p.mask_mode == MASK_RELU) v = p.mask_y[o] > 0.f ? v : 0.f;
-                    else if (p.mask_mode == MASK_SIGMOID) { float y = p.mask_y[o]; v *= y * (1.f - y); }
-                    if (p.out2) p.out2[o] = v;
-                    if (p.addsrc) v += p.addsrc[o];
-                    if (p.accumulate) v += p.out[o];
-                    p.out[o] = v;
+                    ssie_epilogue_elem(p, o, acc[m][r] + bv);
                 }
             }
         }

@@ -585,8 +585,11 @@ template __global__ void conv_wgrad_kernel<32, 64, 9, 4>(const WgradParams);
 template <int OQ>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int nslices, int ntaps, int ci_pad, int co_pad,
                                     int Cin, int Cout, float* __restrict__ dst, long s_co, long s_ci, long s_t,
-                                    const float* __restrict__ bias_slabs, float* __restrict__ db, int accumulate, int accumulate_bias)
+                                    const float* __restrict__ bias_slabs, float* __restrict__ db, int accumulate, int accumulate_bias,
+                                    int co_group, long w_extra, long b_extra)
 {
+    // co_group > 0: the output channels are co_group-sized blocks of DIFFERENT parameter tensors (q | k | v): block j's weights sit
+    // j * w_extra floats further than co * s_co says, its bias j * b_extra further than db + co
     constexpr int SG = 256 / OQ;
     __shared__ f32x4 red[SG][OQ];
     const int lo = threadIdx.x % OQ, sg = threadIdx.x / OQ;
@@ -625,13 +628,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (co + k >= Cout) break;
-            float* d = is_w ? dst + (co + k) * s_co + ci * s_ci + t * s_t : db + co + k;
+            const long blk = co_group ? (co + k) / co_group : 0;
+            float* d = is_w ? dst + (co + k) * s_co + ci * s_ci + t * s_t + blk * w_extra : db + co + k + blk * b_extra;
             *d = (is_w ? accumulate : accumulate_bias) ? (*d + tot[k]) : tot[k];
         }
     }
 }
-template __global__ void wgrad_reduce_kernel<64>(const float*, int, int, int, int, int, int, float*, long, long, long, const float*, float*, int, int);
-template __global__ void wgrad_reduce_kernel<16>(const float*, int, int, int, int, int, int, float*, long, long, long, const float*, float*, int, int);
+template __global__ void wgrad_reduce_kernel<64>(const float*, int, int, int, int, int, int, float*, long, long, long, const float*, float*, int, int, int, long, long);
+template __global__ void wgrad_reduce_kernel<16>(const float*, int, int, int, int, int, int, float*, long, long, long, const float*, float*, int, int, int, long, long);
 
 // per-channel sums of G over all pixels (bias gradient of the transposed conv), two-stage & deterministic.
 // Stage 1: a thread owns one channel quad (float4) and every (256 / quads)-th pixel of the block's range, with four
@@ -684,13 +688,20 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 // weight packing: dst[chunk][t][q][n][s] = W[base + n*s_n + k*s_k + tapsel[t]*s_t], k = chunk*16 + (q>>1)*8 + (q&1)*4 + s
 // ---------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ void ssie_pack_one(const PackDesc& d, long idx4)
+__device__ __forceinline__ void ssie_pack_one(const PackDesc& d, long idx4_in)
 {
-    long total4 = (long)d.nchunks * d.T * 4 * d.Npad;
-    if (idx4 >= total4) return;
-    int n = (int)(idx4 % d.Npad); long r = idx4 / d.Npad;
+    if (d.copy) {                                   // bias vector into its slot of a contiguous one
+        if (idx4_in < d.N) d.dst[d.n_off + idx4_in] = d.w[idx4_in];
+        return;
+    }
+    const int ncols = d.ncnt ? d.ncnt : d.Npad;     // sub-block packs iterate over their own columns only
+    long total4 = (long)d.nchunks * d.T * 4 * ncols;
+    if (idx4_in >= total4) return;
+    int n = (int)(idx4_in % ncols); long r = idx4_in / ncols;
     int q = (int)(r & 3); r >>= 2;
     int t = (int)(r % d.T); int chunk = (int)(r / d.T);
+    // destination slot: row pitch Npad, column n_off + n, chunk shifted by k_off / 16 (fp32 layout; bf16 / Winograd packs are whole-tensor)
+    const long idx4 = (((long)(chunk + (d.k_off >> 4)) * d.T + t) * 4 + q) * d.Npad + d.n_off + n;
     const int ts = (int)d.tapsel[t] * d.s_t;
     if (d.bf16) {          // 8 bf16 (round to nearest even) per 16-byte slot
         const int kb8 = chunk * 32 + q * 8;
@@ -822,7 +833,7 @@ __global__ void pack_weights_batched_kernel(const PackDesc* __restrict__ descs)
         }
         return;
     }
-    long total4 = (long)d.nchunks * d.T * 4 * d.Npad;
+    long total4 = d.copy ? d.N : (long)d.nchunks * d.T * 4 * (d.ncnt ? d.ncnt : d.Npad);
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += (long)gridDim.x * blockDim.x)
         ssie_pack_one(d, idx);
 }
@@ -963,18 +974,18 @@ int ssie_wgrad_reduce_wide_min = 64;      // launches with at least this many sl
 extern "C" void ssie_debug_set_wgrad_reduce_wide_min(int v) { ssie_wgrad_reduce_wide_min = v; }
 int ssie_launch_wgrad_reduce(const float* slabs, int nslices, int ntaps, int ci_pad, int co_pad, int Cin, int Cout,
                              float* dst, long s_co, long s_ci, long s_t, const float* bias_slabs, float* db,
-                             int accumulate, hipStream_t st, int accumulate_bias)
+                             int accumulate, hipStream_t st, int accumulate_bias, int co_group, long w_extra, long b_extra)
 {
     const long cq = (Cout + 3) / 4;
     long total = (long)ntaps * Cin * cq + (bias_slabs ? cq : 0);
     if (nslices >= ssie_wgrad_reduce_wide_min)
         hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st,
                            slabs, nslices, ntaps, ci_pad, co_pad, Cin, Cout, dst, s_co, s_ci, s_t, bias_slabs, db, accumulate,
-                           accumulate_bias < 0 ? accumulate : accumulate_bias);
+                           accumulate_bias < 0 ? accumulate : accumulate_bias, co_group, w_extra, b_extra);
     else
         hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st,
                            slabs, nslices, ntaps, ci_pad, co_pad, Cin, Cout, dst, s_co, s_ci, s_t, bias_slabs, db, accumulate,
-                           accumulate_bias < 0 ? accumulate : accumulate_bias);
+                           accumulate_bias < 0 ? accumulate : accumulate_bias, co_group, w_extra, b_extra);
     return hipGetLastError() == hipSuccess ? 0 : 25;
 }
 
@@ -988,7 +999,7 @@ int ssie_launch_colsum(const float* g, long npix, int cstride, int coff, int C, 
 
 int ssie_launch_pack(const PackDesc& d, hipStream_t st)
 {
-    long total4 = (long)d.nchunks * d.T * 4 * d.Npad;
+    long total4 = d.copy ? d.N : (long)d.nchunks * d.T * 4 * d.Npad;
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, d);
     return hipGetLastError() == hipSuccess ? 0 : 27;
 }

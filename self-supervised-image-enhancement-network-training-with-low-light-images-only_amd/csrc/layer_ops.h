@@ -7,6 +7,7 @@ struct TapList { int n; int8_t dy[SSIE_MAX_TAPS], dx[SSIE_MAX_TAPS], sel[SSIE_MA
 struct Epilogue {
     const float* bias; int act; const float* addsrc; float* out2;
     const float* mask_y; int mask_mode; int accumulate;
+    int out2_mode;          // see ConvParams.out2_mode
 };
 
 TapList ssie_taps_conv(int k);

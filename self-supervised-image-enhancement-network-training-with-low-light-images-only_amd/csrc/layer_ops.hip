@@ -166,6 +166,8 @@ int ssie_make_conv(ConvParams& p, const SrcDesc* srcs, int nsrc, int N, int Hv, 
     p.so = so; p.py = py; p.px = px;
     p.bias = e.bias; p.act = e.act; p.addsrc = e.addsrc; p.out2 = e.out2; p.mask_y = e.mask_y;
     p.mask_mode = e.mask_y ? e.mask_mode : MASK_NONE; p.accumulate = e.accumulate;
+    p.out2_mode = e.out2 ? e.out2_mode : 0;
+    if (p.out2_mode && (!e.mask_y || e.addsrc || e.act != ACT_NONE)) return SSIE_E_ARG;     // modes 1 / 2 are backward-pass forms
     p.tiles_y = ssie_ceil_div(Ho, p.th); p.tiles_x = ssie_ceil_div(Wo, p.tw);
     p.co_blocks = p.Cout_pad > 32 ? p.Cout_pad / 64 : 1;
     return 0;
@@ -240,6 +242,7 @@ static bool taps_are_3x3(const TapList& t)
 int ssie_wino_eligible(const ConvParams& p, const TapList& t)
 {
     if (!taps_are_3x3(t) || p.si != 1 || p.so != 1 || p.py || p.px) return 0;
+    if (p.out2_mode) return 0;          // the Winograd epilogues have no out2_mode forms (adding them cost the F(2x2) kernel 4 %: A/B'd)
     if (p.Ho != p.Hv || p.Wo != p.Wv || p.Hout != p.Ho || p.Wout != p.Wo) return 0;
     if (ssie_fprop_wino4) {
         bool ok = ssie_round_up(p.Wo, 64) * 3 <= p.Wo * 4;

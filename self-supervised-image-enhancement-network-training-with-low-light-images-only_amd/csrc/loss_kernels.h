@@ -47,8 +47,10 @@ int ssie_launch_ingest_bf16(const float* x, long sn, long sc, long sh, long sw, 
 int ssie_launch_ingest(const float* x, long sn, long sc, long sh, long sw, float* out, int N, int C, int H, int W, int cs, hipStream_t st);
 int ssie_launch_mask_axpy(const float* src, int src_cs, const float* y, int y_cs, int mode, float* dst, int dst_cs,
                           long npix, int C, int accumulate, hipStream_t st);
+// optional second output: dst_masked = relu'(mask_y) * (the total written to dst), same geometry as dst (the ReLU-mask launch folded in)
 int ssie_launch_upsample_adjoint(const float* src, int Hv, int Wv, int src_cs, float* dst, int Hs, int Ws, int dst_cs,
-                                 int N, int C, int accumulate, hipStream_t st);
+                                 int N, int C, int accumulate, hipStream_t st,
+                                 const float* mask_y = nullptr, int y_cs = 0, float* dst_masked = nullptr, int dm_cs = 0);
 int ssie_launch_adam(float* p, const float* g, float* m, float* v, long n, float gscale, float lr, int step,
                      float b1, float b2, float eps, hipStream_t st);
 int ssie_fft_supported(int H, int W);

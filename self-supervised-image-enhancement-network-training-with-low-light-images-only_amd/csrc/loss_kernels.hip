@@ -779,7 +779,8 @@ __global__ void mask_axpy_vec_kernel(const float* __restrict__ src, int src_cs, 
 // adjoint of nearest up-sampling (F.interpolate backward): dst[lo] (+)= sum of src[hi] with src_index(hi) == lo
 __global__ void upsample_adjoint_kernel(const float* __restrict__ src, int Hv, int Wv, int src_cs,
                                         float* __restrict__ dst, int Hs, int Ws, int dst_cs, int N, int C,
-                                        float sy, float sx, int accumulate)
+                                        float sy, float sx, int accumulate,
+                                        const float* __restrict__ mask_y, int y_cs, float* __restrict__ dst_masked, int dm_cs)
 {
     const long total = (long)N * Hs * Ws * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -798,8 +799,12 @@ __global__ void upsample_adjoint_kernel(const float* __restrict__ src, int Hv, i
                 s += src[((n * Hv + yy) * (long)Wv + xx) * src_cs + c];
             }
         }
-        float* d = dst + ((n * Hs + y) * (long)Ws + x) * dst_cs + c;
-        *d = accumulate ? *d + s : s;
+        const long pix = (n * Hs + y) * (long)Ws + x;
+        float* d = dst + pix * dst_cs + c;
+        s = accumulate ? *d + s : s;
+        *d = s;
+        // optional second output: the total times relu'(mask_y) (the ReLU-mask launch that used to follow, model.py:157,161)
+        if (dst_masked) dst_masked[pix * dm_cs + c] = mask_y[pix * y_cs + c] > 0.f ? s : 0.f;
     }
 }
 
@@ -808,7 +813,8 @@ __global__ void upsample_adjoint_kernel(const float* __restrict__ src, int Hv, i
 // (pixel, channel quad), 16-byte accesses; the general kernel above searches a 5 x 5 candidate window per element.
 template <int F>
 __global__ void upsample_adjoint_exact_kernel(const float* __restrict__ src, int src_cs, float* __restrict__ dst, int Hs, int Ws, int dst_cs,
-                                              int N, int C4, int accumulate)
+                                              int N, int C4, int accumulate,
+                                              const float* __restrict__ mask_y, int y_cs, float* __restrict__ dst_masked, int dm_cs)
 {
     const long total = (long)N * Hs * Ws * C4;
     const int Wv = Ws * F, Hv = Hs * F;
@@ -822,9 +828,18 @@ __global__ void upsample_adjoint_exact_kernel(const float* __restrict__ src, int
 #pragma unroll
             for (int dx = 0; dx < F; ++dx)
                 s4 += *(const f32x4*)(src + ((n * Hv + (long)y * F + dy) * Wv + (long)x * F + dx) * src_cs + 4 * q);
-        float* d = dst + ((n * Hs + y) * (long)Ws + x) * dst_cs + 4 * q;
+        const long pix = (n * Hs + y) * (long)Ws + x;
+        float* d = dst + pix * dst_cs + 4 * q;
+        f32x4 yv = {0.f, 0.f, 0.f, 0.f};
+        if (dst_masked) yv = *(const f32x4*)(mask_y + pix * y_cs + 4 * q);        // issued with the other loads
         if (accumulate) s4 += *(const f32x4*)d;
         *(f32x4*)d = s4;
+        if (dst_masked) {
+            f32x4 m;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[e] = yv[e] > 0.f ? s4[e] : 0.f;
+            *(f32x4*)(dst_masked + pix * dm_cs + 4 * q) = m;
+        }
     }
 }
 
@@ -945,21 +960,23 @@ int ssie_launch_mask_axpy(const float* src, int src_cs, const float* y, int y_cs
     return hipGetLastError() == hipSuccess ? 0 : 46;
 }
 int ssie_launch_upsample_adjoint(const float* src, int Hv, int Wv, int src_cs, float* dst, int Hs, int Ws, int dst_cs,
-                                 int N, int C, int accumulate, hipStream_t st)
+                                 int N, int C, int accumulate, hipStream_t st, const float* mask_y, int y_cs, float* dst_masked, int dm_cs)
 {
-    const bool al = C % 4 == 0 && src_cs % 4 == 0 && dst_cs % 4 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
+    if (dst_masked && !mask_y) return 49;
+    const bool al = C % 4 == 0 && src_cs % 4 == 0 && dst_cs % 4 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0 &&
+                    (!dst_masked || (y_cs % 4 == 0 && dm_cs % 4 == 0 && (((uintptr_t)mask_y | (uintptr_t)dst_masked) & 15) == 0));
     if (al && Hv == 2 * Hs && Wv == 2 * Ws) {
-        hipLaunchKernelGGL(upsample_adjoint_exact_kernel<2>, dim3(grid_for((long)N * Hs * Ws * (C / 4), 256)), dim3(256), 0, st, src, src_cs, dst, Hs, Ws, dst_cs, N, C / 4, accumulate);
+        hipLaunchKernelGGL(upsample_adjoint_exact_kernel<2>, dim3(grid_for((long)N * Hs * Ws * (C / 4), 256)), dim3(256), 0, st, src, src_cs, dst, Hs, Ws, dst_cs, N, C / 4, accumulate, mask_y, y_cs, dst_masked, dm_cs);
         return hipGetLastError() == hipSuccess ? 0 : 47;
     }
     if (al && Hv == 4 * Hs && Wv == 4 * Ws) {
-        hipLaunchKernelGGL(upsample_adjoint_exact_kernel<4>, dim3(grid_for((long)N * Hs * Ws * (C / 4), 256)), dim3(256), 0, st, src, src_cs, dst, Hs, Ws, dst_cs, N, C / 4, accumulate);
+        hipLaunchKernelGGL(upsample_adjoint_exact_kernel<4>, dim3(grid_for((long)N * Hs * Ws * (C / 4), 256)), dim3(256), 0, st, src, src_cs, dst, Hs, Ws, dst_cs, N, C / 4, accumulate, mask_y, y_cs, dst_masked, dm_cs);
         return hipGetLastError() == hipSuccess ? 0 : 47;
     }
     const float sy = (Hs == Hv) ? 1.f : (float)Hs / (float)Hv, sx = (Ws == Wv) ? 1.f : (float)Ws / (float)Wv;
     hipLaunchKernelGGL(upsample_adjoint_kernel, dim3(grid_for((long)N * Hs * Ws * C, 256)), dim3(256), 0, st,
-                       src, Hv, Wv, src_cs, dst, Hs, Ws, dst_cs, N, C, sy, sx, accumulate);
-    return hipGetLastError() == hipSuccess ? 0 : 47;
+                       src, Hv, Wv, src_cs, dst, Hs, Ws, dst_cs, N, C, sy, sx, accumulate, mask_y, y_cs, dst_masked, dm_cs);
+    return hipGetLastError() == hipSuccess ? 0 : 48;
 }
 int ssie_launch_adam(float* p, const float* g, float* m, float* v, long n, float gscale, float lr, int step,
                      float b1, float b2, float eps, hipStream_t st)

@@ -71,6 +71,8 @@ struct Plan {
     std::vector<Fn> fwdi;        // enhance-only forward in fp32: `fwd` with its last three launches replaced by the fused tail
     size_t npacks_train = 0;     // packs[0 .. npacks_train) belong to the fp32 lists, the rest to fwd16
     bool bound = false;
+    bool fold_masks = true;      // captured at creation (ssie_debug_set_fold_masks): ReLU / sigmoid mask launches folded into the producing launches
+    bool qkv_fused = true;       // captured at creation (ssie_debug_set_qkv_fused): the dry build and the bound build must walk the same packs
     bool fused_tail = true;      // captured at creation (ssie_debug_set_fused_tail): the dry build and the bound build must agree
     // the slab reductions (HBM-bound) run on a side stream underneath the next MFMA-bound launches; wgrad launches
     // alternate between two slab areas so that a reduction only has to finish before the wgrad AFTER the next one
@@ -352,21 +354,25 @@ struct Builder {
         return 0;
     }
 
-    Epilogue bwd_epi(const char* mask_y, int mask_mode, int accumulate)
+    // out2 / out2_mode (ConvParams.out2_mode): 1 = out receives the masked gradient and out2 the unmasked one; 2 = out accumulates the
+    // unmasked total and out2 receives the masked total - a ReLU / sigmoid mask launch folded into the producing data gradient
+    Epilogue bwd_epi(const char* mask_y, int mask_mode, int accumulate, const char* out2 = nullptr, int out2_mode = 0)
     {
         Epilogue e; memset(&e, 0, sizeof(e));
         e.mask_y = (mask_y && !dry) ? pl.buf(mask_y) : nullptr; e.mask_mode = mask_y ? mask_mode : 0; e.accumulate = accumulate;
+        e.out2 = (out2 && !dry) ? pl.buf(out2) : nullptr; e.out2_mode = out2 ? out2_mode : 0;
         return e;
     }
 
     // data gradient of a forward conv layer w.r.t. input channels [ci_off, ci_off + cs)
     int dgrad(std::vector<Fn>& ops, const LayerP& L, int stride, const char* g, int g_coff, int ci_off, int cs,
-              const char* gx, const char* mask_y, int mask_mode, int accumulate)
+              const char* gx, const char* mask_y, int mask_mode, int accumulate, const char* out2 = nullptr, int out2_mode = 0)
     {
         const int T = L.k * L.k;
         const BufInfo& gb = pl.bi(g); const BufInfo& xb = pl.bi(gx);
         SrcDesc in = ssie_make_src(ptr(g), ssie_round_up(L.cout, 4), gb.cs, g_coff, gb.H, gb.W, gb.H, gb.W);
-        Epilogue e = bwd_epi(mask_y, mask_mode, accumulate);
+        Epilogue e = bwd_epi(mask_y, mask_mode, accumulate, out2, out2_mode);
+        if (out2 && (stride != 1 || pl.bi(out2).cs != xb.cs || pl.bi(out2).H != xb.H || pl.bi(out2).W != xb.W)) return SSIE_E_ARG;
         const float* wbase = dry ? nullptr : pl.P + L.w + (size_t)ci_off * T;
         if (stride == 1) {
             TapList t = ssie_taps_dgrad_s1(L.k);
@@ -388,7 +394,7 @@ struct Builder {
     // weight gradient (+ fused bias gradient when with_bias) of a forward conv layer, one input source per call
     // nbatch = 2: x and g name the pass-1 halves of [pass 1 ; pass 2] pairs and the launch covers both passes
     int wgrad(std::vector<Fn>& ops, const LayerP& L, int stride, SrcDesc x, int creal, int Hv, int Wv, int ci_off, const char* g,
-              int g_coff = 0, bool with_bias = false, int nbatch = 1)
+              int g_coff = 0, bool with_bias = false, int nbatch = 1, int co_group = 0, long w_extra = 0, long b_extra = 0)
     {
         if (dry) return 0;
         const int T = L.k * L.k, pad = (L.k - 1) / 2;
@@ -419,8 +425,57 @@ struct Builder {
             const double hs = x.Hs < Hv ? x.Hs : Hv, ws = x.Ws < Wv ? x.Ws : Wv;
             ops.back().bytes = 4.0 * ((double)pl.N * nbatch * (hs * ws * creal + (double)Ho * Wo * cout) + (double)need + (double)bneed);
         }
-        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, p.nslices, p.ntaps, p.ci_pad, p.co_pad, creal, cout, dw, s_co, T, 1, bslab, db, 1, st); }, K_WGRAD_REDUCE, 0.0, "", sl, SLAB_READ));
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, p.nslices, p.ntaps, p.ci_pad, p.co_pad, creal, cout, dw, s_co, T, 1, bslab, db, 1, st, -1, co_group, w_extra, b_extra); }, K_WGRAD_REDUCE, 0.0, "", sl, SLAB_READ));
         ops.back().bytes = 4.0 * ((double)need + (double)bneed + 2.0 * (double)creal * cout * T);   // ... and read once by the reduction (dW read-modify-write)
+        return 0;
+    }
+
+    // q_linear | k_linear | v_linear (model.py:93-95, 104-106) as one 64 -> 192 1 x 1 layer into "qkv": three sub-block weight packs and
+    // three bias copies fill one packed operand / one contiguous bias vector (the three parameter tensors are not adjacent)
+    int qkv_fwd(std::vector<Fn>& ops)
+    {
+        const std::string i = "illum_adjust_net.attn.";
+        const LayerP L3[3] = {layer(pl, i + "q_linear"), layer(pl, i + "k_linear"), layer(pl, i + "v_linear")};
+        TapList t = ssie_taps_conv(1);
+        float* wp = take_pack(ssie_packed_floats(64, 192, 1));
+        float* bp = take_pack(192);
+        if (dry) return 0;
+        for (int j = 0; j < 3; ++j) {
+            PackDesc d = ssie_make_pack(pl.P + L3[j].w, wp, 64, 64, t, 1, 64, 1);
+            d.Npad = 192; d.n_off = 64 * j; d.ncnt = 64;
+            pl.packs.push_back(d);
+            PackDesc c; memset(&c, 0, sizeof(c)); c.copy = 1; c.w = pl.P + L3[j].b; c.dst = bp; c.N = 64; c.n_off = 64 * j;
+            pl.packs.push_back(c);
+        }
+        const BufInfo& ob = pl.bi("qkv");
+        Epilogue e; memset(&e, 0, sizeof(e)); e.bias = bp; e.act = ACT_NONE;
+        SrcDesc in = src("a3", 64, pl.H8, pl.W8);
+        ConvParams p;
+        int rc = ssie_make_conv(p, &in, 1, pl.N, pl.H8, pl.W8, t, 1, pl.H8, pl.W8, wp, 192, pl.buf("qkv"), ob.H, ob.W, ob.cs, 0, 1, 0, 0, e);
+        if (rc) return rc;
+        push(ops, p, 64);
+        return 0;
+    }
+    // data gradient of the same layer: gt3 += mask(a3) * W_qkv^T gqkv, K = 192 gradient channels from the three weight tensors
+    int qkv_dgrad(std::vector<Fn>& ops)
+    {
+        const std::string i = "illum_adjust_net.attn.";
+        const LayerP L3[3] = {layer(pl, i + "q_linear"), layer(pl, i + "k_linear"), layer(pl, i + "v_linear")};
+        TapList t = ssie_taps_dgrad_s1(1);
+        float* wp = take_pack(ssie_packed_floats(192, 64, 1));
+        if (dry) return 0;
+        for (int j = 0; j < 3; ++j) {
+            PackDesc d = ssie_make_pack(pl.P + L3[j].w, wp, 64, 64, t, 64, 1, 1);      // K = output channel of the layer, N = its input channel
+            d.k_off = 64 * j; d.ncnt = 64;
+            pl.packs.push_back(d);
+        }
+        const BufInfo& gb = pl.bi("gqkv"); const BufInfo& xb = pl.bi("gt3");
+        SrcDesc in = ssie_make_src(pl.buf("gqkv"), 192, gb.cs, 0, gb.H, gb.W, gb.H, gb.W);
+        Epilogue e = bwd_epi("a3", MASK_RELU, 1);
+        ConvParams p;
+        int rc = ssie_make_conv(p, &in, 1, pl.N, gb.H, gb.W, t, 1, xb.H, xb.W, wp, 64, pl.buf("gt3"), xb.H, xb.W, xb.cs, 0, 1, 0, 0, e);
+        if (rc) return rc;
+        push(ops, p, 192);
         return 0;
     }
 
@@ -491,19 +546,26 @@ struct Builder {
         return 0;
     }
 
-    void upadj(std::vector<Fn>& ops, const char* src, int Hv, int Wv, const char* dst, int accumulate)
+    // mask_y / masked: also write masked = relu'(mask_y) * (the total left in dst) - the mask launch that used to follow
+    void upadj(std::vector<Fn>& ops, const char* src, int Hv, int Wv, const char* dst, int accumulate, const char* mask_y = nullptr,
+               const char* masked = nullptr)
     {
         if (dry) return;
         const BufInfo& db = pl.bi(dst);
         const float* sp = pl.buf(src); float* dp = pl.buf(dst);
         const int scs = pl.bi(src).cs, dcs = db.cs, Hs = db.H, Ws = db.W, N = pl.N;
-        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_upsample_adjoint(sp, Hv, Wv, scs, dp, Hs, Ws, dcs, N, 64, accumulate, st); }, K_ELEMENTWISE, 0.0, "upsample_adjoint"));
-        ops.back().bytes = 4.0 * N * 64.0 * ((double)Hv * Wv + (double)Hs * Ws * (accumulate ? 2.0 : 1.0));
+        const float* yp = mask_y ? pl.buf(mask_y) : nullptr; float* mp = masked ? pl.buf(masked) : nullptr;
+        const int ycs = mask_y ? pl.bi(mask_y).cs : 0, mcs = masked ? pl.bi(masked).cs : 0;
+        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_upsample_adjoint(sp, Hv, Wv, scs, dp, Hs, Ws, dcs, N, 64, accumulate, st, yp, ycs, mp, mcs); },
+                         K_ELEMENTWISE, 0.0, masked ? "upsample_adjoint + relu mask" : "upsample_adjoint"));
+        ops.back().bytes = 4.0 * N * 64.0 * ((double)Hv * Wv + (double)Hs * Ws * ((accumulate ? 2.0 : 1.0) + (masked ? 2.0 : 0.0)));
     }
 };
 
 #define CK(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
 
+int g_fold_masks = 1;    // ssie_debug_set_fold_masks: 0 = the backward's activation masks as separate mask_axpy launches (plans created afterwards)
+int g_qkv_fused = 1;     // ssie_debug_set_qkv_fused: 0 = q / k / v as three 64 -> 64 launches each way (plans created afterwards)
 int g_skinny_final = 1;  // ssie_debug_set_skinny_final: 0 = final_conv (64 -> 1) on the MFMA tile kernels like every other layer
 
 int build_decomposition_fwd(Builder& b, std::vector<Fn>& ops, const char* xin, int p)
@@ -562,9 +624,11 @@ int build_illum_fwd(Builder& b, std::vector<Fn>& ops, bool fused_tail = false)
     CK(b.conv(ops, layer(pl, i + "conv2.0"), {b.src("a1", 64, H2, W2)}, H2, W2, 2, "a2", ACT_RELU));
     CK(b.conv(ops, layer(pl, i + "conv3.0"), {b.src("a2", 64, H4, W4)}, H4, W4, 2, "a3", ACT_RELU));
     // TransformerBlock (model.py:99-119): tokens = NHWC pixels of a3
-    CK(b.conv(ops, layer(pl, i + "attn.q_linear"), {b.src("a3", 64, H8, W8)}, H8, W8, 1, "qkv", ACT_NONE, nullptr, nullptr, 0));
-    CK(b.conv(ops, layer(pl, i + "attn.k_linear"), {b.src("a3", 64, H8, W8)}, H8, W8, 1, "qkv", ACT_NONE, nullptr, nullptr, 64));
-    CK(b.conv(ops, layer(pl, i + "attn.v_linear"), {b.src("a3", 64, H8, W8)}, H8, W8, 1, "qkv", ACT_NONE, nullptr, nullptr, 128));
+    if (b.h16 || !pl.qkv_fused) {
+        CK(b.conv(ops, layer(pl, i + "attn.q_linear"), {b.src("a3", 64, H8, W8)}, H8, W8, 1, "qkv", ACT_NONE, nullptr, nullptr, 0));
+        CK(b.conv(ops, layer(pl, i + "attn.k_linear"), {b.src("a3", 64, H8, W8)}, H8, W8, 1, "qkv", ACT_NONE, nullptr, nullptr, 64));
+        CK(b.conv(ops, layer(pl, i + "attn.v_linear"), {b.src("a3", 64, H8, W8)}, H8, W8, 1, "qkv", ACT_NONE, nullptr, nullptr, 128));
+    } else CK(b.qkv_fwd(ops));
     if (!b.dry) {
         const float* qkv = pl.buf("qkv"); float* ao = pl.buf("ao"); float* lse = pl.buf("lse");
         const int N = pl.N, T = H8 * W8;
@@ -707,19 +771,23 @@ int build_illum_bwd(Builder& b, std::vector<Fn>& ops)
     CK(b.wgrad(ops, Lu, 1, b.src("d1", 64, H4, W4), 64, H4, W4, 0, "Gf4"));
     CK(b.wgrad(ops, Lu, 1, b.src("d2", 64, H2, W2), 64, H2, W2, 64, "Gf2"));
     CK(b.wgrad(ops, Lu, 1, b.src("d3", 64, H, W), 64, H, W, 128, "Gf", 0, true));
-    CK(b.dgrad(ops, Lu, 1, "Gf", 0, 128, 64, "gd3", nullptr, 0, 0));
+    // level H: d3 = relu(e3) + a0 - the data gradient w.r.t. d3 goes to a0 as it is (gd3) and to e3 through relu'(u3) (Ge3): both from
+    // the one launch (out2_mode 1), instead of a mask launch over the full-resolution tensor
+    if (pl.fold_masks) CK(b.dgrad(ops, Lu, 1, "Gf", 0, 128, 64, "Ge3", "u3", MASK_RELU, 0, "gd3", 1));
+    else CK(b.dgrad(ops, Lu, 1, "Gf", 0, 128, 64, "gd3", nullptr, 0, 0));
     CK(b.dgrad(ops, Lu, 1, "Gf2", 0, 64, 64, "gd2", nullptr, 0, 0));
     CK(b.dgrad(ops, Lu, 1, "Gf4", 0, 0, 64, "gd1", nullptr, 0, 0));
-    // level H: d3 = relu(e3) + a0
-    b.mask_axpy(ops, "gd3", "u3", MASK_RELU, "Ge3", 64, 0);
+    if (!pl.fold_masks) b.mask_axpy(ops, "gd3", "u3", MASK_RELU, "Ge3", 64, 0);
     CK(b.wgrad(ops, Ld3, 1, b.src("d2", 64, H, W), 64, H, W, 0, "Ge3", 0, true));
-    CK(b.dgrad(ops, Ld3, 1, "Ge3", 0, 0, 64, "tmpH", nullptr, 0, 0)); b.upadj(ops, "tmpH", H, W, "gd2", 1);
+    CK(b.dgrad(ops, Ld3, 1, "Ge3", 0, 0, 64, "tmpH", nullptr, 0, 0));
     // level H/2: d2 = relu(e2) + a1.  tmpH is reused with the (H2, W2) geometry through a view buffer
-    b.mask_axpy(ops, "gd2", "u2", MASK_RELU, "Ge2", 64, 0);
+    if (pl.fold_masks) b.upadj(ops, "tmpH", H, W, "gd2", 1, "u2", "Ge2");
+    else { b.upadj(ops, "tmpH", H, W, "gd2", 1); b.mask_axpy(ops, "gd2", "u2", MASK_RELU, "Ge2", 64, 0); }
     CK(b.wgrad(ops, Ld2, 1, b.src("d1", 64, H2, W2), 64, H2, W2, 0, "Ge2", 0, true));
-    CK(b.dgrad(ops, Ld2, 1, "Ge2", 0, 0, 64, "tmpH2", nullptr, 0, 0)); b.upadj(ops, "tmpH2", H2, W2, "gd1", 1);
+    CK(b.dgrad(ops, Ld2, 1, "Ge2", 0, 0, 64, "tmpH2", nullptr, 0, 0));
     // level H/4
-    b.mask_axpy(ops, "gd1", "u1", MASK_RELU, "Ge1", 64, 0);
+    if (pl.fold_masks) b.upadj(ops, "tmpH2", H2, W2, "gd1", 1, "u1", "Ge1");
+    else { b.upadj(ops, "tmpH2", H2, W2, "gd1", 1); b.mask_axpy(ops, "gd1", "u1", MASK_RELU, "Ge1", 64, 0); }
     CK(b.wgrad(ops, Ld1, 1, b.src("t3", 64, H4, W4), 64, H4, W4, 0, "Ge1", 0, true));
     CK(b.dgrad(ops, Ld1, 1, "Ge1", 0, 0, 64, "tmpH4", nullptr, 0, 0)); b.upadj(ops, "tmpH4", H4, W4, "gt3", 0);
     // TransformerBlock backward: t3 = a3 + ff2(relu(ff1(attn(q,k,v(a3)))))
@@ -733,14 +801,25 @@ int build_illum_bwd(Builder& b, std::vector<Fn>& ops)
         const int N = pl.N, T = H8 * W8;
         ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_attn_bwd(qkv, 192, ao, gao, 64, lse, delta, gqkv, N, T, st); }, K_ATTN, 8.0 * N * 4 * (double)T * T * 16));
     }
-    CK(b.wgrad(ops, Lq, 1, b.src("a3", 64, H8, W8), 64, H8, W8, 0, "gqkv", 0, true));
-    CK(b.wgrad(ops, Lk, 1, b.src("a3", 64, H8, W8), 64, H8, W8, 0, "gqkv", 64, true));
-    CK(b.wgrad(ops, Lv, 1, b.src("a3", 64, H8, W8), 64, H8, W8, 0, "gqkv", 128, true));
     // g(a3) = [gt3 + dgrad_q + dgrad_k + dgrad_v] * relu'(a3)
-    b.mask_axpy(ops, "gt3", "a3", MASK_RELU, "gt3", 64, 0);
-    CK(b.dgrad(ops, Lq, 1, "gqkv", 0, 0, 64, "gt3", "a3", MASK_RELU, 1));
-    CK(b.dgrad(ops, Lk, 1, "gqkv", 64, 0, 64, "gt3", "a3", MASK_RELU, 1));
-    CK(b.dgrad(ops, Lv, 1, "gqkv", 128, 0, 64, "gt3", "a3", MASK_RELU, 1));
+    if (!pl.qkv_fused) {
+        CK(b.wgrad(ops, Lq, 1, b.src("a3", 64, H8, W8), 64, H8, W8, 0, "gqkv", 0, true));
+        CK(b.wgrad(ops, Lk, 1, b.src("a3", 64, H8, W8), 64, H8, W8, 0, "gqkv", 64, true));
+        CK(b.wgrad(ops, Lv, 1, b.src("a3", 64, H8, W8), 64, H8, W8, 0, "gqkv", 128, true));
+        b.mask_axpy(ops, "gt3", "a3", MASK_RELU, "gt3", 64, 0);
+        CK(b.dgrad(ops, Lq, 1, "gqkv", 0, 0, 64, "gt3", "a3", MASK_RELU, 1));
+        CK(b.dgrad(ops, Lk, 1, "gqkv", 64, 0, 64, "gt3", "a3", MASK_RELU, 1));
+        CK(b.dgrad(ops, Lv, 1, "gqkv", 128, 0, 64, "gt3", "a3", MASK_RELU, 1));
+    } else {
+        // q | k | v as ONE 64 -> 192 layer (model.py:104-106 apply three Linear layers to the same tokens): one weight-gradient launch
+        // whose reduction scatters the three 64-row blocks into the three parameter tensors, one data-gradient launch over K = 192
+        const long wx = (long)(Lk.w - Lq.w) - 64 * 64, bx = (long)(Lk.b - Lq.b) - 64;
+        if ((long)(Lv.w - Lk.w) - 64 * 64 != wx || (long)(Lv.b - Lk.b) - 64 != bx) return SSIE_E_ARG;
+        LayerP Lqkv = Lq; Lqkv.cout = 192;
+        CK(b.wgrad(ops, Lqkv, 1, b.src("a3", 64, H8, W8), 64, H8, W8, 0, "gqkv", 0, true, 1, 64, wx, bx));
+        b.mask_axpy(ops, "gt3", "a3", MASK_RELU, "gt3", 64, 0);
+        CK(b.qkv_dgrad(ops));
+    }
     CK(b.wgrad(ops, Lc3, 2, b.src("a2", 64, H4, W4), 64, H4, W4, 0, "gt3", 0, true));
     b.mask_axpy(ops, "gd1", "a2", MASK_RELU, "gd1", 64, 0);
     CK(b.dgrad(ops, Lc3, 2, "gt3", 0, 0, 64, "gd1", "a2", MASK_RELU, 1));
@@ -750,6 +829,8 @@ int build_illum_bwd(Builder& b, std::vector<Fn>& ops)
     CK(b.wgrad(ops, Lc1, 2, b.src("a0", 64, H, W), 64, H, W, 0, "gd2", 0, true));
     CK(b.dgrad(ops, Lc1, 2, "gd2", 0, 0, 64, "gd3", nullptr, 0, 1));
     CK(b.wgrad(ops, Lc0, 1, b.src("RL_1", pl.CRL, H, W), pl.B + 1, H, W, 0, "gd3", 0, true));
+    // (the sigmoid mask gRL -> G8 that follows stays its own launch: this data gradient runs on the Winograd kernel, whose epilogue has no
+    // second-output forms - adding them slowed every Winograd launch by 4 %)
     CK(b.dgrad(ops, Lc0, 1, "gd3", 0, 0, pl.B + 1, "gRL", nullptr, 0, 1));
     return 0;
 }
@@ -905,7 +986,7 @@ extern "C" void* ssie_plan_create(int N, int bands, int H, int W, const float* c
 {
     if (N < 1 || bands < 2 || H < 8 || W < 8 || (H & 1) || (W & 1)) return nullptr;   // model.py:59 needs even H, W
     Plan* pl = new Plan();
-    pl->N = N; pl->B = bands; pl->H = H; pl->W = W; pl->fused_tail = g_fused_tail != 0;
+    pl->N = N; pl->B = bands; pl->H = H; pl->W = W; pl->fused_tail = g_fused_tail != 0; pl->qkv_fused = g_qkv_fused != 0; pl->fold_masks = g_fold_masks != 0;
     pl->CX = ssie_round_up(bands, 4); pl->CRL = ssie_round_up(bands + 1, 4);
     pl->H2 = (H + 1) / 2; pl->W2 = (W + 1) / 2; pl->H4 = (pl->H2 + 1) / 2; pl->W4 = (pl->W2 + 1) / 2;
     pl->H8 = (pl->H4 + 1) / 2; pl->W8 = (pl->W4 + 1) / 2;
@@ -938,6 +1019,8 @@ extern "C" int ssie_plan_set_graph(void* h, int on)
     return 0;
 }
 extern "C" void ssie_debug_set_spectral9(int on) { g_spectral9 = on; }
+extern "C" void ssie_debug_set_qkv_fused(int on) { g_qkv_fused = on; }
+extern "C" void ssie_debug_set_fold_masks(int on) { g_fold_masks = on; }
 extern "C" void ssie_debug_set_skinny_final(int on) { g_skinny_final = on; }   // takes effect for plans created afterwards
 extern "C" void ssie_debug_set_fused_tail(int on) { g_fused_tail = on; }     // takes effect for plans bound afterwards
 extern "C" void ssie_plan_destroy(void* h) { delete (Plan*)h; }

@@ -76,6 +76,9 @@ struct ConvParams {
     int out_bf16;           // bf16 inference kernel only: element type of `out` (addsrc / out2 are always bf16 there)
     int wino;               // 1: geometry and weights (U = G g G^T, 16 transform positions) of conv_wino_kernel (conv_wino.hip); 2: of conv_wino4_kernel (36 positions)
     int tconv;              // 1: all four output-parity classes of a stride-2 transposed 3 x 3 convolution in one launch (conv_tconv.hip)
+    int out2_mode;          // what `out2` receives (fp32 kernels; conv_device.h ssie_epilogue_*): 0 = act(v) after the mask, before the skip add
+                            // (the pre-skip copy of the forward); 1 = v BEFORE the mask (one launch writes a gradient and its masked copy:
+                            // out = mask * v, out2 = v); 2 = the mask applied to the ACCUMULATED total (out = old + v unmasked, out2 = mask * out)
     int out2_cstride;       // bf16 inference kernel only: elements per pixel of `out2` when it differs from out_cstride (0 = the same) -
                             // the fp32 R|I output (B + 1 padded to 4) and its bf16 twin (padded to 8) at band counts like 64 or 256
 };
@@ -106,6 +109,10 @@ struct PackDesc {
     int K, N, Npad, T, nchunks;
     int s_k, s_n, s_t;
     int8_t tapsel[SSIE_MAX_TAPS];
+    // sub-block packs (several weight tensors into ONE packed operand, e.g. q | k | v as a 64 -> 192 layer): this descriptor fills output
+    // columns [n_off, n_off + N) of rows Npad wide (ncnt = N: iterate over its own columns only; 0 = over Npad) and input channels
+    // [k_off, k_off + K) (k_off a multiple of 16).  copy = 1: dst[n_off + i] = w[i], i < N (a bias vector into a contiguous one)
+    int n_off, ncnt, k_off, copy;
     int bf16;               // 1: pack for the bf16 kernel - dst[chunk32][t][slot 0..3][n][8 bf16], k = chunk*32 + 8*slot + s
     int wino;               // 1: Winograd F(2x2,3x3) weights - dst[chunk][xi 0..15][q][n][4] = (G g G^T)[xi], tapsel[r*3+s] = source tap of g[r][s]
                             // 2: Winograd F(4x4,3x3) weights - dst[step of 8][n / 32][xi 0..35][(n % 32) / 16][pair g][n % 16][2] (conv_wino4.hip)
@@ -124,7 +131,7 @@ extern int ssie_fprop_use_v2;                          // tuning / A-B switch (1
 int ssie_launch_wgrad(const WgradParams& p, hipStream_t st);
 int ssie_launch_wgrad_reduce(const float* slabs, int nslices, int ntaps, int ci_pad, int co_pad, int Cin, int Cout,
                              float* dst, long s_co, long s_ci, long s_t, const float* bias_slabs, float* db,
-                             int accumulate, hipStream_t st, int accumulate_bias = -1);
+                             int accumulate, hipStream_t st, int accumulate_bias = -1, int co_group = 0, long w_extra = 0, long b_extra = 0);
 int ssie_launch_wgrad_wino(const WgradParams& p, hipStream_t st);                      // conv_wgrad_wino.hip
 int ssie_launch_colsum(const float* g, long npix, int cstride, int coff, int C, float* partial, int nblk,
                        float* dst, int accumulate, hipStream_t st);
