@@ -68,10 +68,46 @@ __device__ __forceinline__ f32x4 ssie_load_virtual(const SrcSel& s, int n, int v
 // 16 operands back-to-back BEFORE using them: a load -> use -> store chain per element exposes one HBM latency per
 // element (16-32 per tile), which is what made the masked data-gradient launches ~40 % slower than the plain ones.
 #define SSIE_EOFF(r) ((long)((r) >> 3) * rowstride + (long)(((r) & 3) + 8 * (((r) >> 2) & 1)) * pixstride)
-template <typename PT>
+template <int EPI = 0, typename PT>
 __device__ __forceinline__ void ssie_epilogue_full(const PT& p, const f32x16& acc, size_t o0, long rowstride, long pixstride, float bv)
 {
     float v[16];
+    if (EPI == 1) {            // plain forward layer (ssie_epi_shape): bias + ReLU / nothing
+        if (p.act == ACT_RELU) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[r] + bv, 0.f);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[r] + bv;
+        }
+        float* ob = p.out + o0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ob[SSIE_EOFF(r)] = v[r];
+        return;
+    }
+    if (EPI == 2) {            // plain data gradient: optional ReLU mask, optional accumulate
+        float* ob = p.out + o0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[r];
+        if (p.mask_mode != MASK_NONE) {
+            const float* mp = p.mask_y + o0;
+            float y[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[r] = mp[SSIE_EOFF(r)];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = y[r] > 0.f ? v[r] : 0.f;
+        }
+        if (p.accumulate) {
+            float a[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] = ob[SSIE_EOFF(r)];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += a[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ob[SSIE_EOFF(r)] = v[r];
+        return;
+    }
     if (p.act == ACT_RELU) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[r] + bv, 0.f);

@@ -56,7 +56,9 @@ __device__ __forceinline__ const f32x4* ssie_virtual_addr(const SrcSel& s, bool 
 // issue / epilogue / barrier phases of one run underneath the MFMA phase of the other (tools/stamp_v2.py: those phases
 // are ~20 % of a lock-stepped 8-wave workgroup's time)
 // TH = 16: stride-1 layers; TH = 8: stride-2 layers (8 x 16 output positions read a 17 x 33 halo)
-template <int NT, int NA2, int NW, int TH>
+// EPI / RAG: epilogue shape (ssie_epi_shape) and "some tile sticks out of the output"; the plain / whole-tile instantiations carry a
+// fraction of the epilogue code (instantiated for the stride-2 geometry only, the one that runs at bench sizes)
+template <int NT, int NA2, int NW, int TH, int EPI = 0, bool RAG = true>
 __global__ __launch_bounds__(64 * NW, 2) void conv_fprop_v2_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -238,14 +240,14 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fprop_v2_kernel(const ConvPar
             const float bv = bv_tile;
             const long rowstride = (long)p.so * p.Wout * p.out_cstride;
             const long pixstride = (long)p.so * p.out_cstride;
-            const bool full = a0 + TH <= p.Ho && b0 + SSIE_TW <= p.Wo &&
-                              (a0 + TH - 1) * p.so + p.py < p.Hout && (b0 + SSIE_TW - 1) * p.so + p.px < p.Wout;
+            const bool full = !RAG || (a0 + TH <= p.Ho && b0 + SSIE_TW <= p.Wo &&
+                                       (a0 + TH - 1) * p.so + p.py < p.Hout && (b0 + SSIE_TW - 1) * p.so + p.px < p.Wout);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int mt = wm * MT + m;
                 const int arow = a0 + 2 * mt, bcol = b0 + 4 * h;
                 const size_t o0 = ((size_t)(n * p.Hout + arow * p.so + p.py) * p.Wout + bcol * p.so + p.px) * p.out_cstride + p.out_coff + co;
-                if (full) { ssie_epilogue_full(p, acc[m], o0, rowstride, pixstride, bv); continue; }
+                if (full) { ssie_epilogue_full<EPI>(p, acc[m], o0, rowstride, pixstride, bv); continue; }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int tr = r >> 3, tc = (r & 3) + 8 * ((r >> 2) & 1);
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fprop_v2_kernel(const ConvPar
 // SINGLE = the virtual input is one tensor (no concat): the source descriptor is then a compile-time choice and the two
 // unused descriptors never occupy scalar registers (the kernel spills ~130 SGPRs to VGPR lanes otherwise, and every
 // restore is a v_readlane + wait states inside the per-step DMA-issue phase).
-template <int NA2, bool SINGLE>
+template <int NA2, bool SINGLE, int EPI = 0, bool RAG = true>
 __global__ __launch_bounds__(512, 2) void conv_fprop_v2w_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -456,8 +458,8 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_v2w_kernel(const ConvParams
         {
             const long rowstride = (long)p.so * p.Wout * p.out_cstride;
             const long pixstride = (long)p.so * p.out_cstride;
-            const bool full = a0 + TH <= p.Ho && b0 + TWW <= p.Wo &&
-                              (a0 + TH - 1) * p.so + p.py < p.Hout && (b0 + TWW - 1) * p.so + p.px < p.Wout;
+            const bool full = !RAG || (a0 + TH <= p.Ho && b0 + TWW <= p.Wo &&
+                                       (a0 + TH - 1) * p.so + p.py < p.Hout && (b0 + TWW - 1) * p.so + p.px < p.Wout);
 #pragma unroll
             for (int c = 0; c < NT; ++c) {
                 const int co = co0 + c * 32 + li;
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_v2w_kernel(const ConvParams
                 for (int m = 0; m < MT; ++m) {
                     const int arow = a0 + 2 * wave, bcol = b0 + 16 * m + 4 * h;
                     const size_t o0 = ((size_t)(n * p.Hout + arow * p.so + p.py) * p.Wout + bcol * p.so + p.px) * p.out_cstride + p.out_coff + co;
-                    if (full) ssie_epilogue_full(p, acc[m][c], o0, rowstride, pixstride, bv);
+                    if (full) ssie_epilogue_full<EPI>(p, acc[m][c], o0, rowstride, pixstride, bv);
                     else ssie_epilogue_ragged(p, acc[m][c], o0, rowstride, pixstride, bv, arow, bcol);
                 }
             }
@@ -481,8 +483,13 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_v2w_kernel(const ConvParams
 
 #define INST_V2(NT, NA2, NW, TH) template __global__ void conv_fprop_v2_kernel<NT, NA2, NW, TH>(const ConvParams);
 INST_V2(1, 3, 8, 16) INST_V2(1, 5, 8, 16) INST_V2(2, 3, 8, 16) INST_V2(2, 5, 8, 16) INST_V2(1, 6, 4, 16) INST_V2(2, 5, 8, 8)
-template __global__ void conv_fprop_v2w_kernel<5, false>(const ConvParams);
-template __global__ void conv_fprop_v2w_kernel<5, true>(const ConvParams);
+#define INST_V2S(E) template __global__ void conv_fprop_v2_kernel<2, 5, 8, 8, E, false>(const ConvParams);
+INST_V2S(0) INST_V2S(1) INST_V2S(2)
+#define INST_V2W(S) template __global__ void conv_fprop_v2w_kernel<5, S, 0, true>(const ConvParams); \
+                    template __global__ void conv_fprop_v2w_kernel<5, S, 0, false>(const ConvParams); \
+                    template __global__ void conv_fprop_v2w_kernel<5, S, 1, false>(const ConvParams); \
+                    template __global__ void conv_fprop_v2w_kernel<5, S, 2, false>(const ConvParams);
+INST_V2W(false) INST_V2W(true)
 
 size_t ssie_fprop_v2_lds_bytes(const ConvParams& p, int nt)
 {
@@ -508,16 +515,22 @@ static int g_v2_split_min_tiles = 1024;   // ... for launches with at least this
 extern "C" void ssie_debug_set_fprop_v2_split(int on) { g_v2_split = on; }
 extern "C" void ssie_debug_set_fprop_v2_split_min_tiles(int v) { g_v2_split_min_tiles = v; }
 
-template <int NT, int NA2, int NW, int TH = 16>
+template <int NT, int NA2, int NW, int TH = 16, int EPI = 0, bool RAG = true>
 static int launch_v2_t(const ConvParams& p, size_t lds, hipStream_t st)
 {
     static unsigned seen = 0;
-    ssie_allow_full_lds((const void*)conv_fprop_v2_kernel<NT, NA2, NW, TH>, seen);
+    ssie_allow_full_lds((const void*)conv_fprop_v2_kernel<NT, NA2, NW, TH, EPI, RAG>, seen);
     const size_t tiles = (size_t)p.N * p.tiles_y * p.tiles_x * p.co_blocks;
     const size_t cap = NW == 8 ? 256 : 512;
     const size_t wgs = tiles < cap ? tiles : cap;
-    hipLaunchKernelGGL((conv_fprop_v2_kernel<NT, NA2, NW, TH>), dim3((unsigned)wgs), dim3(64 * NW), lds, st, p);
+    hipLaunchKernelGGL((conv_fprop_v2_kernel<NT, NA2, NW, TH, EPI, RAG>), dim3((unsigned)wgs), dim3(64 * NW), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : 18;
+}
+
+// every tile of the launch lies inside the output (so the element-wise edge epilogue is never needed)
+static bool whole_tiles(const ConvParams& p, int th, int tw)
+{
+    return p.Ho % th == 0 && p.Wo % tw == 0 && (p.Ho - 1) * p.so + p.py < p.Hout && (p.Wo - 1) * p.so + p.px < p.Wout;
 }
 
 int ssie_launch_fprop_v2(const ConvParams& p, hipStream_t st)
@@ -525,13 +538,17 @@ int ssie_launch_fprop_v2(const ConvParams& p, hipStream_t st)
     const int nt = (p.Cout_pad % 64 == 0) ? 2 : 1;
     if (p.tw == 32) {      // geometry built for the wide kernel (ssie_make_conv)
         const size_t lds = ssie_fprop_v2_lds_bytes(p, 2);
-        static unsigned seen_a = 0, seen_b = 0;
-        ssie_allow_full_lds((const void*)conv_fprop_v2w_kernel<5, false>, seen_a);
-        ssie_allow_full_lds((const void*)conv_fprop_v2w_kernel<5, true>, seen_b);
         const size_t tiles = (size_t)p.N * p.tiles_y * p.tiles_x * p.co_blocks;
         const dim3 grid((unsigned)(tiles < 256 ? tiles : 256));
-        if (p.nsrc == 1) hipLaunchKernelGGL((conv_fprop_v2w_kernel<5, true>), grid, dim3(512), lds, st, p);
-        else hipLaunchKernelGGL((conv_fprop_v2w_kernel<5, false>), grid, dim3(512), lds, st, p);
+        const int epi = ssie_epi_shape(p);
+        const bool rag = !whole_tiles(p, 16, 32);
+        static unsigned seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define V2W_GO(S, E, R, SLOT) { ssie_allow_full_lds((const void*)conv_fprop_v2w_kernel<5, S, E, R>, seen[SLOT]); \
+                                hipLaunchKernelGGL((conv_fprop_v2w_kernel<5, S, E, R>), grid, dim3(512), lds, st, p); }
+#define V2W_PICK(S, B) { if (rag) V2W_GO(S, 0, true, B) else if (epi == 1) V2W_GO(S, 1, false, B + 1) else if (epi == 2) V2W_GO(S, 2, false, B + 2) else V2W_GO(S, 0, false, B + 3) }
+        if (p.nsrc == 1) V2W_PICK(true, 0) else V2W_PICK(false, 4)
+#undef V2W_PICK
+#undef V2W_GO
         return hipGetLastError() == hipSuccess ? 0 : 19;
     }
     // 32-channel layers: two 4-wave workgroups per CU (both must fit the LDS, and there must be enough tiles to fill
@@ -549,7 +566,12 @@ int ssie_launch_fprop_v2(const ConvParams& p, hipStream_t st)
     }
     const int na2 = (p.hp_h * p.hp_w * 4 + 511) / 512;
     const size_t lds = ssie_fprop_v2_lds_bytes(p, nt);
-    if (p.th == 8) return launch_v2_t<2, 5, 8, 8>(p, lds, st);
+    if (p.th == 8) {
+        if (!whole_tiles(p, 8, SSIE_TW)) return launch_v2_t<2, 5, 8, 8>(p, lds, st);
+        const int epi = ssie_epi_shape(p);
+        return epi == 1 ? launch_v2_t<2, 5, 8, 8, 1, false>(p, lds, st) : epi == 2 ? launch_v2_t<2, 5, 8, 8, 2, false>(p, lds, st)
+                                                                                  : launch_v2_t<2, 5, 8, 8, 0, false>(p, lds, st);
+    }
     if (nt == 2) return na2 <= 3 ? launch_v2_t<2, 3, 8>(p, lds, st) : launch_v2_t<2, 5, 8>(p, lds, st);
     return na2 <= 3 ? launch_v2_t<1, 3, 8>(p, lds, st) : launch_v2_t<1, 5, 8>(p, lds, st);
 }

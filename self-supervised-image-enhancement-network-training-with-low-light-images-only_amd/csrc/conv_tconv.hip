@@ -23,6 +23,7 @@ constexpr int TC_BSZ = 9 * 4 * 64;                                              
 __device__ __forceinline__ constexpr int tc_class(int t) { return t == 0 ? 0 : t < 3 ? 1 : t < 5 ? 2 : 3; }
 }
 
+template <int EPI, bool RAG>       // epilogue shape (ssie_epi_shape) / some tile sticks out of the output: see conv_fprop_v2_kernel
 __global__ __launch_bounds__(512, 2) void conv_tconv_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -142,10 +143,10 @@ __global__ __launch_bounds__(512, 2) void conv_tconv_kernel(const ConvParams p)
 #define TC_EPI(C, M)                                                                                          \
                 {                                                                                             \
                     constexpr int py_ = (C) >> 1, px_ = (C) & 1;                                              \
-                    const bool full_ = 2 * (a0 + TC_TH - 1) + py_ < p.Hout && 2 * (b0 + TC_TW - 1) + px_ < p.Wout; \
+                    const bool full_ = !RAG || (2 * (a0 + TC_TH - 1) + py_ < p.Hout && 2 * (b0 + TC_TW - 1) + px_ < p.Wout); \
                     const int arow_ = a0 + 2 * (wm * MT + (M)), bcol_ = b0 + 4 * h;                           \
                     const size_t o0_ = ((size_t)(n * p.Hout + 2 * arow_ + py_) * p.Wout + 2 * bcol_ + px_) * p.out_cstride + p.out_coff + co; \
-                    if (full_) ssie_epilogue_full(p, acc[M][C], o0_, rowstride, pixstride, bv);               \
+                    if (full_) ssie_epilogue_full<EPI>(p, acc[M][C], o0_, rowstride, pixstride, bv);          \
                     else {                                                                                    \
                         _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) {                                   \
                             const int tr_ = r_ >> 3, tcn_ = (r_ & 3) + 8 * ((r_ >> 2) & 1);                   \
@@ -181,9 +182,14 @@ int ssie_launch_tconv(const ConvParams& p, hipStream_t st)
     if (p.ntaps != 9 || p.si != 1 || p.so != 2 || p.nsrc != 1 || p.Cout_pad != 64 || p.th != TC_TH || p.tw != TC_TW ||
         p.hp_h != TC_HP || p.hp_w != TC_HP || p.min_dy != 0 || p.min_dx != 0) return 51;
     if (p.src[0].sy != 1.f || p.src[0].sx != 1.f || p.src[0].Hs != p.Hv || p.src[0].Ws != p.Wv) return 52;
-    static unsigned seen = 0;
-    ssie_allow_full_lds((const void*)conv_tconv_kernel, seen);
     const size_t tiles = (size_t)p.N * p.tiles_y * p.tiles_x;
-    hipLaunchKernelGGL(conv_tconv_kernel, dim3((unsigned)(tiles < 256 ? tiles : 256)), dim3(512), ssie_tconv_lds_bytes(), st, p);
+    const dim3 grid((unsigned)(tiles < 256 ? tiles : 256));
+    const bool rag = p.Ho % TC_TH != 0 || p.Wo % TC_TW != 0 || p.Hout != 2 * p.Ho || p.Wout != 2 * p.Wo;
+    const int epi = ssie_epi_shape(p);
+    static unsigned seen[4] = {0, 0, 0, 0};
+#define TC_GO(E, R, SLOT) { ssie_allow_full_lds((const void*)conv_tconv_kernel<E, R>, seen[SLOT]); \
+                            hipLaunchKernelGGL((conv_tconv_kernel<E, R>), grid, dim3(512), ssie_tconv_lds_bytes(), st, p); }
+    if (rag) TC_GO(0, true, 0) else if (epi == 1) TC_GO(1, false, 1) else if (epi == 2) TC_GO(2, false, 2) else TC_GO(0, false, 3)
+#undef TC_GO
     return hipGetLastError() == hipSuccess ? 0 : 53;
 }

@@ -98,9 +98,46 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_a
 namespace {
 // 16 outputs of one lane = (tile column 4g + r, r = k&3) x (pixel e = k>>2 of the 2 x 2 tile), one channel; o0 includes 8g pixels
 #define WN_EOFF(k) ((long)((k) >> 3) * rowstride + (long)(2 * ((k) & 3) + (((k) >> 2) & 1)) * pixstride)
-template <typename PT>
+// EPI (conv_wino_kernel): 0 = every fused form; 1 = forward layers with bias + ReLU / nothing only; 2 = data gradients with an optional ReLU
+// mask and accumulate only.  The kernel is sensitive to what its epilogue carries (round 4: two more run-time branches here cost every
+// launch 4 %), so the two common shapes get instantiations without the forms they never use
+template <int EPI, typename PT>
 __device__ __forceinline__ void wino_epilogue16(const PT& p, float v[16], size_t o0, long rowstride, long pixstride, float bv)
 {
+    if (EPI == 1) {
+        if (p.act == ACT_RELU) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = fmaxf(v[k] + bv, 0.f);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] += bv;
+        }
+        float* ob = p.out + o0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) ob[WN_EOFF(k)] = v[k];
+        return;
+    }
+    if (EPI == 2) {
+        float* ob = p.out + o0;
+        if (p.mask_mode != MASK_NONE) {
+            const float* mp = p.mask_y + o0;
+            float y[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) y[k] = mp[WN_EOFF(k)];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = y[k] > 0.f ? v[k] : 0.f;
+        }
+        if (p.accumulate) {
+            float a[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[k] = ob[WN_EOFF(k)];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] += a[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) ob[WN_EOFF(k)] = v[k];
+        return;
+    }
     if (p.act == ACT_RELU) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) v[k] = fmaxf(v[k] + bv, 0.f);
@@ -171,7 +208,7 @@ __device__ __forceinline__ void wino_epilogue16_ragged(const PT& p, const float 
 }
 }  // namespace
 
-template <bool SINGLE, bool UP>
+template <bool SINGLE, bool UP, int EPI, bool RAG>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -312,7 +349,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
         float bv[2];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) bv[c] = (p.bias && co0 + 16 * c + tx < p.Cout) ? p.bias[co0 + 16 * c + tx] : 0.f;
+        for (int c = 0; c < 2; ++c) bv[c] = (EPI != 2 && p.bias && co0 + 16 * c + tx < p.Cout) ? p.bias[co0 + 16 * c + tx] : 0.f;
         int ntile = 0x7fffffff;
         int nn = n, na0 = a0, nb0 = b0, nco0 = co0;
 
@@ -387,9 +424,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const bool more = step + 1 < nsteps;
                     const int r0 = wave >= 4 ? SSIE_WINO_DMA_ROW_HI : SSIE_WINO_DMA_ROW_LO;
                     if (!SSIE_WINO_DMA_SPLIT || UP) {
-                        if (i == r0) {
-                            if (more) WN_PREFETCH(step + 1, n, a0, b0, co0, buf ^ 1, 0)
-                            else if (ntile < total_tiles) WN_PREFETCH(0, nn, na0, nb0, nco0, buf ^ 1, 0)
+                        // ONE prefetch site (the next K chunk of this tile, or chunk 0 of the next tile, chosen by scalar selects): two
+                        // sites doubled the DMA code of the hot path, and this kernel is faster the less code it carries (round 4)
+                        if (i == r0 && (more || ntile < total_tiles)) {
+                            const int ps = more ? step + 1 : 0, pn = more ? n : nn, pa0 = more ? a0 : na0, pb0 = more ? b0 : nb0, pco0 = more ? co0 : nco0;
+                            WN_PREFETCH(ps, pn, pa0, pb0, pco0, buf ^ 1, 0)
                         }
                     } else {
                         if (i == r0) {
@@ -418,7 +457,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         {
             const long rowstride = (long)p.Wout * p.out_cstride, pixstride = p.out_cstride;
             const int oy0 = a0 + 2 * wave, ox0 = b0 + 8 * g;
-            const bool full = a0 + W_TH <= p.Hout && b0 + W_TW <= p.Wout;
+            const bool full = !RAG || (a0 + W_TH <= p.Hout && b0 + W_TW <= p.Wout);      // RAG = false: the output is whole 16 x 32 tiles
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const int co = co0 + 16 * c + tx;
@@ -436,7 +475,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     y[8 + r] = s0[1] - s0[2] - s0[3]; y[12 + r] = s1[1] - s1[2] - s1[3];
                 }
                 const size_t o0 = ((size_t)(n * p.Hout + oy0) * p.Wout + ox0) * p.out_cstride + p.out_coff + co;
-                if (full) wino_epilogue16(p, y, o0, rowstride, pixstride, bv[c]);
+                if (full) wino_epilogue16<EPI>(p, y, o0, rowstride, pixstride, bv[c]);
                 else wino_epilogue16_ragged(p, y, o0, rowstride, pixstride, bv[c], oy0, ox0);
             }
         }
@@ -453,10 +492,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef WN_BLDS
 }
 
-template __global__ void conv_wino_kernel<false, false>(const ConvParams);
-template __global__ void conv_wino_kernel<true, false>(const ConvParams);
-template __global__ void conv_wino_kernel<false, true>(const ConvParams);
-template __global__ void conv_wino_kernel<true, true>(const ConvParams);
+#define WINO_INST(S, U) template __global__ void conv_wino_kernel<S, U, 0, true>(const ConvParams); \
+                        template __global__ void conv_wino_kernel<S, U, 1, true>(const ConvParams); \
+                        template __global__ void conv_wino_kernel<S, U, 2, true>(const ConvParams); \
+                        template __global__ void conv_wino_kernel<S, U, 0, false>(const ConvParams); \
+                        template __global__ void conv_wino_kernel<S, U, 1, false>(const ConvParams); \
+                        template __global__ void conv_wino_kernel<S, U, 2, false>(const ConvParams);
+WINO_INST(false, false) WINO_INST(true, false) WINO_INST(false, true) WINO_INST(true, true)
+#undef WINO_INST
 
 
 size_t ssie_wino_lds_bytes() { return (size_t)(2 * W_HPB + 2 * W_BSZ) * 16 + 64 + (size_t)W_HPB * 4; }
@@ -465,11 +508,6 @@ int ssie_launch_fprop_wino(const ConvParams& p, hipStream_t st)
 {
     if (p.ntaps != 9 || p.si != 1 || p.so != 1 || p.py || p.px || p.min_dy != -1 || p.min_dx != -1 || p.Cout_pad % 32) return 31;
     if (p.th != W_TH || p.tw != W_TW || p.hp_h != W_HPH || p.hp_w != W_HPW || p.co_blocks != p.Cout_pad / 32) return 32;
-    static unsigned seen[4] = {0, 0, 0, 0};
-    ssie_allow_full_lds((const void*)conv_wino_kernel<false, false>, seen[0]);
-    ssie_allow_full_lds((const void*)conv_wino_kernel<true, false>, seen[1]);
-    ssie_allow_full_lds((const void*)conv_wino_kernel<false, true>, seen[2]);
-    ssie_allow_full_lds((const void*)conv_wino_kernel<true, true>, seen[3]);
     const size_t tiles = (size_t)p.N * p.tiles_y * p.tiles_x * p.co_blocks;
     const dim3 grid((unsigned)(tiles < 256 ? tiles : 256));
     const size_t lds = ssie_wino_lds_bytes();
@@ -478,9 +516,22 @@ int ssie_launch_fprop_wino(const ConvParams& p, hipStream_t st)
     for (int s = 0; s < p.nsrc; ++s)
         up = up || p.src[s].sy != 1.f || p.src[s].sx != 1.f || (size_t)(W_HPH * p.Wv + W_HPW) * p.src[s].cstride * 4 >= (1u << 24) ||
              (size_t)p.Hv * p.Wv * p.src[s].cstride * 4 >= (1u << 31);       // (and an image must fit a 32-bit num_records)
-    if (p.nsrc == 1 && !up) hipLaunchKernelGGL((conv_wino_kernel<true, false>), grid, dim3(512), lds, st, p);
-    else if (p.nsrc == 1) hipLaunchKernelGGL((conv_wino_kernel<true, true>), grid, dim3(512), lds, st, p);
-    else if (!up) hipLaunchKernelGGL((conv_wino_kernel<false, false>), grid, dim3(512), lds, st, p);
-    else hipLaunchKernelGGL((conv_wino_kernel<false, true>), grid, dim3(512), lds, st, p);
+    // epilogue shape (see wino_epilogue16): 1 = plain forward layer, 2 = plain data gradient, 0 = anything else
+    const bool plain = !p.out2 && !p.addsrc;
+    const int epi = (plain && !p.mask_y && !p.accumulate && p.act != ACT_SIGMOID) ? 1
+                  : (plain && !p.bias && p.act == ACT_NONE && p.mask_mode != MASK_SIGMOID) ? 2 : 0;
+    const bool rag = p.Hout % W_TH != 0 || p.Wout % W_TW != 0;       // some tile sticks out of the output: keep the element-wise epilogue
+    static unsigned seen[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define WINO_GO(S, U, E, SLOT) { if (rag) { ssie_allow_full_lds((const void*)conv_wino_kernel<S, U, E, true>, seen[SLOT]); \
+                                            hipLaunchKernelGGL((conv_wino_kernel<S, U, E, true>), grid, dim3(512), lds, st, p); } \
+                                 else { ssie_allow_full_lds((const void*)conv_wino_kernel<S, U, E, false>, seen[12 + SLOT]); \
+                                        hipLaunchKernelGGL((conv_wino_kernel<S, U, E, false>), grid, dim3(512), lds, st, p); } }
+#define WINO_EPI(S, U, SLOT) { if (epi == 1) WINO_GO(S, U, 1, SLOT + 1) else if (epi == 2) WINO_GO(S, U, 2, SLOT + 2) else WINO_GO(S, U, 0, SLOT) }
+    if (p.nsrc == 1 && !up) WINO_EPI(true, false, 0)
+    else if (p.nsrc == 1) WINO_EPI(true, true, 3)
+    else if (!up) WINO_EPI(false, false, 6)
+    else WINO_EPI(false, true, 9)
+#undef WINO_EPI
+#undef WINO_GO
     return hipGetLastError() == hipSuccess ? 0 : 33;
 }

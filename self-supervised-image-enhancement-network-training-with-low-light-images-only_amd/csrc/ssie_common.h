@@ -83,6 +83,18 @@ struct ConvParams {
                             // the fp32 R|I output (B + 1 padded to 4) and its bf16 twin (padded to 8) at band counts like 64 or 256
 };
 
+// Epilogue shape of a launch (template parameter EPI of the persistent fprop kernels): 1 = plain forward layer (bias + ReLU / nothing),
+// 2 = plain data gradient (optional ReLU mask, optional accumulate), 0 = anything else.  The persistent kernels are measurably faster the
+// less epilogue code they carry (round 4: the general + edge-tile epilogue made conv_wino_kernel 75 KB of code, the plain forms 28 KB,
+// -5 % time), so the two common shapes get their own instantiations.
+static inline int ssie_epi_shape(const ConvParams& p)
+{
+    const bool plain = !p.out2 && !p.addsrc;
+    if (plain && !p.mask_y && !p.accumulate && p.act != ACT_SIGMOID) return 1;
+    if (plain && !p.bias && p.act == ACT_NONE && p.mask_mode != MASK_SIGMOID) return 2;
+    return 0;
+}
+
 struct WgradParams {
     SrcDesc src;            // the layer input (single source per launch)
     int N, Hv, Wv;
