@@ -98,9 +98,43 @@ __device__ __forceinline__ f32x2 pk_fnma(f32x2 a, f32x2 k, f32x2 c) { f32x2 r; a
 
 // one output row of a tile pair = 2 x 4 consecutive pixels of one channel: v[0..3] tile A, v[4..7] tile B (4 * pixstride further... the
 // tiles are neighbours: 8 consecutive pixels).  Fused operands are loaded for all 8 elements before use.
-template <typename PT>
+template <int EPI, typename PT>     // EPI: epilogue shape (ssie_epi_shape, ssie_common.h)
 __device__ __forceinline__ void wino4_epilogue8(const PT& p, float v[8], size_t o0, long pixstride, float bv)
 {
+    if (EPI == 1) {
+        if (p.act == ACT_RELU) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] + bv, 0.f);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += bv;
+        }
+        float* ob = p.out + o0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ob[k * pixstride] = v[k];
+        return;
+    }
+    if (EPI == 2) {
+        float* ob = p.out + o0;
+        if (p.mask_mode != MASK_NONE) {
+            const float* mp = p.mask_y + o0;
+            float y[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) y[k] = mp[k * pixstride];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = y[k] > 0.f ? v[k] : 0.f;
+        }
+        if (p.accumulate) {
+            float a[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = ob[k * pixstride];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += a[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ob[k * pixstride] = v[k];
+        return;
+    }
     if (p.act == ACT_RELU) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] + bv, 0.f);
@@ -171,7 +205,7 @@ __device__ __forceinline__ void wino4_epilogue8_ragged(const PT& p, const float 
 
 }  // namespace
 
-template <bool SINGLE>
+template <bool SINGLE, int EPI, bool RAG>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino4_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -277,7 +311,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     while (tile < total_tiles) {
         f32x4 acc[36];
         const int co = cb * 32 + nh * 16 + tx;
-        const float bv = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+        const float bv = (EPI != 2 && p.bias && co < p.Cout) ? p.bias[co] : 0.f;
         int ntile = 0x7fffffff;
         int nn = n, na0 = a0, nb0 = b0, ncb = cb;
 
@@ -407,7 +441,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (co < p.Cout) {
 #endif
             const long pixstride = p.out_cstride;
-            const bool full = a0 + V_TH <= p.Hout && b0 + V_TW <= p.Wout;
+            const bool full = !RAG || (a0 + V_TH <= p.Hout && b0 + V_TW <= p.Wout);
             const int oy0 = a0 + 4 * wm;
 #pragma unroll
             for (int rp = 0; rp < 2; ++rp) {
@@ -429,7 +463,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const f32x2 y0 = pk_add(pk_add(t[yy][0], s1), s2), y1 = pk_fma(d2, k2, d1), y2 = pk_fma(s2, k4, s1), y3 = pk_add(pk_fma(d2, k8, d1), t[yy][5]);
                     float yv[8] = {y0.x, y1.x, y2.x, y3.x, y0.y, y1.y, y2.y, y3.y};
                     const size_t o0 = ((size_t)(n * p.Hout + oy0 + yy) * p.Wout + ox0) * p.out_cstride + p.out_coff + co;
-                    if (full) wino4_epilogue8(p, yv, o0, pixstride, bv);
+                    if (full) wino4_epilogue8<EPI>(p, yv, o0, pixstride, bv);
                     else wino4_epilogue8_ragged(p, yv, o0, pixstride, bv, oy0 + yy, ox0);
                 }
             }
@@ -450,8 +484,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef V4_AOFF
 }
 
-template __global__ void conv_wino4_kernel<false>(const ConvParams);
-template __global__ void conv_wino4_kernel<true>(const ConvParams);
 
 size_t ssie_wino4_lds_bytes() { return (size_t)(2 * V_HP + 2 * V_BSZ) * 16 + 64; }
 
@@ -463,14 +495,18 @@ int ssie_launch_fprop_wino4(const ConvParams& p, hipStream_t st)
     for (int s = 0; s < p.nsrc; ++s)
         if (p.src[s].sy != 1.f || p.src[s].sx != 1.f || p.src[s].Hs != p.Hv || p.src[s].Ws != p.Wv ||
             (size_t)(V_HPH * p.Wv + V_HPW) * p.src[s].cstride * 4 >= (1u << 24) || (size_t)p.Hv * p.Wv * p.src[s].cstride * 4 >= (1u << 31)) return 36;
-    static unsigned seen[2] = {0, 0};
-    ssie_allow_full_lds((const void*)conv_wino4_kernel<false>, seen[0]);
-    ssie_allow_full_lds((const void*)conv_wino4_kernel<true>, seen[1]);
     const size_t tiles = (size_t)p.N * p.tiles_y * p.tiles_x * p.co_blocks;
     const dim3 grid((unsigned)(tiles < 256 ? tiles : 256));
     const size_t lds = ssie_wino4_lds_bytes();
     if (lds > 160 * 1024) return 37;
-    if (p.nsrc == 1) hipLaunchKernelGGL((conv_wino4_kernel<true>), grid, dim3(512), lds, st, p);
-    else hipLaunchKernelGGL((conv_wino4_kernel<false>), grid, dim3(512), lds, st, p);
+    const int epi = ssie_epi_shape(p);
+    const bool rag = p.Hout % V_TH != 0 || p.Wout % V_TW != 0;
+    static unsigned seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define W4_GO(S, E, R, SLOT) { ssie_allow_full_lds((const void*)conv_wino4_kernel<S, E, R>, seen[SLOT]); \
+                               hipLaunchKernelGGL((conv_wino4_kernel<S, E, R>), grid, dim3(512), lds, st, p); }
+#define W4_PICK(S, B) { if (rag) W4_GO(S, 0, true, B) else if (epi == 1) W4_GO(S, 1, false, B + 1) else if (epi == 2) W4_GO(S, 2, false, B + 2) else W4_GO(S, 0, false, B + 3) }
+    if (p.nsrc == 1) W4_PICK(true, 0) else W4_PICK(false, 4)
+#undef W4_PICK
+#undef W4_GO
     return hipGetLastError() == hipSuccess ? 0 : 38;
 }

@@ -9,9 +9,10 @@ import bench
 
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    bands = int(sys.argv[2]) if len(sys.argv) > 2 else 31           # usage: profile_ops.py [N [bands]]
     torch.manual_seed(41)
-    net = model.LowLightEnhance(input_channels=31, lr=1e-3, **bench.JYU).to("cuda")
-    x = bench.synth(N, 31, 128, 41, "cuda")
+    net = model.LowLightEnhance(input_channels=bands, lr=1e-3, **bench.JYU).to("cuda")
+    x = bench.synth(N, bands, 128, 41, "cuda")
     for _ in range(3):
         net.train_step(x)
     plan = net._plan_for(x)

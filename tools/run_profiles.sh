@@ -4,7 +4,7 @@
 # committed summaries under profiles/.   usage: bash tools/run_profiles.sh r02_mid [workloads...]
 set -o pipefail
 TAG=${1:-r03}; shift
-WL=${@:-"train31 train256 infer1024_bf16"}
+WL=${@:-"train31 train64 train256 infer1024_bf16"}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -13,6 +13,7 @@ for w in $WL; do
   case $w in
     train31)  PARGS="--workload train31 --steps 3 --warmup 2 --no-cpu-baseline --no-roofline";;
     train256) PARGS="--workload train256 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline";;
+    train64)  PARGS="--workload train64 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline";;
     infer1024_bf16) PARGS="--workload infer1024_bf16 --steps 3 --warmup 2 --no-cpu-baseline --no-roofline";;
     infer1024_f32) PARGS="--workload infer1024_f32 --steps 3 --warmup 2 --no-cpu-baseline --no-roofline";;
   esac
@@ -33,6 +34,7 @@ for w in $WL; do
   case $w in
     train31)  ARGS="--workload train31";;
     train256) ARGS="--workload train256 --steps 10 --warmup 3";;
+    train64)  ARGS="--workload train64";;
     infer1024_bf16) ARGS="--workload infer1024_bf16 --steps 50 --warmup 10";;
     infer1024_f32) ARGS="--workload infer1024_f32 --steps 20 --warmup 5";;
   esac
