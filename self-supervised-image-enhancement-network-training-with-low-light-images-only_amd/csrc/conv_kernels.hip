@@ -47,7 +47,7 @@ extern "C" int ssie_debug_set_stamp_buffer(void* buf)
 // step s run; only the short register -> LDS commit sits between two barriers.
 // TH: output tile rows (8 or 16; the tile is TH x 16 positions = TH/2 MFMA M-tiles).  The 16-row tile halves the
 // weight staging, the barriers and the tile boundaries per MFMA and is used for the stride-1 3x3 / 1x1 layers.
-template <int NT, int NA, int TH>
+template <int NT, int NA, int TH, int EPI = 0, bool RAG = true>      // EPI / RAG: epilogue shape and "some tile sticks out" (ssie_epi_shape)
 __global__ __launch_bounds__(256, ((NA <= 3 && TH == 8) ? 3 : 2)) void conv_fprop_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -229,14 +229,14 @@ __global__ __launch_bounds__(256, ((NA <= 3 && TH == 8) ? 3 : 2)) void conv_fpro
             const float bv = p.bias ? p.bias[co] : 0.f;
             const long rowstride = (long)p.so * p.Wout * p.out_cstride;
             const long pixstride = (long)p.so * p.out_cstride;
-            const bool full = a0 + TH <= p.Ho && b0 + SSIE_TW <= p.Wo &&
-                              (a0 + TH - 1) * p.so + p.py < p.Hout && (b0 + SSIE_TW - 1) * p.so + p.px < p.Wout;
+            const bool full = !RAG || (a0 + TH <= p.Ho && b0 + SSIE_TW <= p.Wo &&
+                                       (a0 + TH - 1) * p.so + p.py < p.Hout && (b0 + SSIE_TW - 1) * p.so + p.px < p.Wout);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int mt = wm * MT + m;
                 const int arow = a0 + 2 * mt, bcol = b0 + 4 * h;
                 const size_t o0 = ((size_t)(n * p.Hout + arow * p.so + p.py) * p.Wout + bcol * p.so + p.px) * p.out_cstride + p.out_coff + co;
-                if (full) ssie_epilogue_full(p, acc[m], o0, rowstride, pixstride, bv);
+                if (full) ssie_epilogue_full<EPI>(p, acc[m], o0, rowstride, pixstride, bv);
                 else ssie_epilogue_ragged(p, acc[m], o0, rowstride, pixstride, bv, arow, bcol);
             }
         }
@@ -258,6 +258,11 @@ __global__ __launch_bounds__(256, ((NA <= 3 && TH == 8) ? 3 : 2)) void conv_fpro
 #define INST_FPROP(NT, NA, TH) template __global__ void conv_fprop_kernel<NT, NA, TH>(const ConvParams);
 INST_FPROP(1, 3, 8) INST_FPROP(1, 6, 8) INST_FPROP(1, 9, 8) INST_FPROP(2, 3, 8) INST_FPROP(2, 6, 8) INST_FPROP(2, 9, 8)
 INST_FPROP(1, 6, 16) INST_FPROP(2, 6, 16)
+// whole-tile / plain-epilogue forms of the 8 x 16-tile kernels (the small launches: batch 1-2, the pyramid's low levels)
+#define INST_FPROP_S(NT, NA) template __global__ void conv_fprop_kernel<NT, NA, 8, 0, false>(const ConvParams); \
+                             template __global__ void conv_fprop_kernel<NT, NA, 8, 1, false>(const ConvParams); \
+                             template __global__ void conv_fprop_kernel<NT, NA, 8, 2, false>(const ConvParams);
+INST_FPROP_S(1, 3) INST_FPROP_S(1, 6) INST_FPROP_S(1, 9) INST_FPROP_S(2, 3) INST_FPROP_S(2, 6) INST_FPROP_S(2, 9)
 
 __device__ f32x4 ssie_zero_page_w[4];     // zero-initialised: source of the padding slots of the wgrad DMA staging
 #define GLDS16W(gptr, lptr)                                                                            \
@@ -850,17 +855,29 @@ extern "C" size_t ssie_fprop_lds_bytes(const ConvParams* p, int nt)
 int ssie_fprop_wgs_per_cu = 3;
 extern "C" void ssie_debug_set_fprop_wgs_per_cu(int v) { ssie_fprop_wgs_per_cu = v < 1 ? 1 : v; }
 
-template <int NT, int NA, int TH>
-static int launch_fprop_t(const ConvParams& p, size_t lds, hipStream_t st)
+template <int NT, int NA, int TH, int EPI, bool RAG>
+static int launch_fprop_e(const ConvParams& p, size_t lds, hipStream_t st)
 {
     static unsigned seen = 0;
-    ssie_allow_full_lds((const void*)conv_fprop_kernel<NT, NA, TH>, seen);
+    ssie_allow_full_lds((const void*)conv_fprop_kernel<NT, NA, TH, EPI, RAG>, seen);
     const size_t tiles = (size_t)p.N * p.tiles_y * p.tiles_x * p.co_blocks;
     const int per_cu = (int)((160 * 1024) / lds);
     size_t wgs = (size_t)256 * (per_cu < 1 ? 1 : (per_cu > ssie_fprop_wgs_per_cu ? ssie_fprop_wgs_per_cu : per_cu));
     if (wgs > tiles) wgs = tiles;
-    hipLaunchKernelGGL((conv_fprop_kernel<NT, NA, TH>), dim3((unsigned)wgs), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv_fprop_kernel<NT, NA, TH, EPI, RAG>), dim3((unsigned)wgs), dim3(256), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : 14;
+}
+
+template <int NT, int NA, int TH>
+static int launch_fprop_t(const ConvParams& p, size_t lds, hipStream_t st)
+{
+    // 8-row tiles: the whole-tile instantiations by epilogue shape where every tile lies inside the output (ssie_epi_shape)
+    if constexpr (TH == 8) if (p.Ho % 8 == 0 && p.Wo % SSIE_TW == 0 && (p.Ho - 1) * p.so + p.py < p.Hout && (p.Wo - 1) * p.so + p.px < p.Wout) {
+        const int epi = ssie_epi_shape(p);
+        return epi == 1 ? launch_fprop_e<NT, NA, 8, 1, false>(p, lds, st) : epi == 2 ? launch_fprop_e<NT, NA, 8, 2, false>(p, lds, st)
+                                                                                   : launch_fprop_e<NT, NA, 8, 0, false>(p, lds, st);
+    }
+    return launch_fprop_e<NT, NA, TH, 0, true>(p, lds, st);
 }
 
 int ssie_fprop_use_v2 = 1;

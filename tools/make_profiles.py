@@ -40,7 +40,10 @@ def find(d, pat):
 def main():
     tag = sys.argv[1]
     src = os.path.join(ROOT, "gpurun_out", tag)
-    workloads = sorted({os.path.basename(p)[:-len("_bench.json")] for p in glob.glob(os.path.join(src, "*_bench.json"))})
+    # (the PMC / stats directories exist before the bench lines do: run_profiles.sh calls this once in between, so that the bench lines
+    # can quote the traffic of their own session)
+    workloads = sorted({os.path.basename(p)[:-len("_bench.json")] for p in glob.glob(os.path.join(src, "*_bench.json"))}
+                       | {os.path.basename(p)[:-len(sfx)] for sfx in ("_stats", "_fetch") for p in glob.glob(os.path.join(src, "*" + sfx)) if os.path.isdir(p)})
     for w in workloads:
         st = find(os.path.join(src, w + "_stats"), "*kernel_stats.csv")
         if st:

@@ -34,4 +34,4 @@ for cin, cout, hw, N in shapes:
         err = (o[:2].double().cpu() - ref).abs().max().item() / ref.abs().max().item()
         us = e0.elapsed_time(e1) / 20 * 1e3
         print(f"conv {cin}->{cout} {hw}x{hw} N{N} {name:11s}: {us:7.1f} us per call (pack + conv)  {2.0 * N * hw * hw * cin * cout * 9 / us / 1e6:6.1f} TFLOP/s direct-equivalent  max err / max|ref| {err:.2e}", flush=True)
-    L.ssie_debug_set_wino4_min_tiles(-1); L.ssie_debug_set_wino_min_tiles(256)
+    L.ssie_debug_set_wino4_min_tiles(-1); L.ssie_debug_set_wino_min_tiles(-1)               # the library's default
