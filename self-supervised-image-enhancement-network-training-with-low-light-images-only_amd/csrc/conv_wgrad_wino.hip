@@ -23,6 +23,9 @@ __device__ f32x4 wgw_zero_page[4];     // zero-initialised: source of the paddin
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),            \
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
+#ifndef SSIE_WGW_REGSTAGE
+#define SSIE_WGW_REGSTAGE 0         // 1: the next position tile through registers (ordinary loads + ds_write) instead of LDS-DMA: A/B'd in round 4, 14.49 against 14.41 ms per step (equal at 256 bands) - not adopted
+#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // packed add / subtract as inline asm (hipcc splits float2 arithmetic whose lanes feed MFMAs one by one) + the fence that stands
 // in for the VALU-write -> MFMA-read wait states the hazard recognizer cannot see behind an asm (conv_wino.hip)
@@ -170,12 +173,58 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }                                                                                                     \
     }
 
+    // Round-4 experiment (SSIE_WGW_REGSTAGE, off): the NEXT tile through registers instead of LDS-DMA (plain sources).  An LDS-DMA piece holds
+    // its wave at issue for 230-470 cycles (stamped in conv_wino4.hip) and this kernel runs ONE wave per SIMD with 20 pieces
+    // per wave and position tile, so ordinary buffer loads (which do not block at issue) behind the barrier + 20 ds_write_b128 behind the
+    // tile's MFMAs looked like a win; measured 0.5 % SLOWER on the step - the stall is not what bounds this kernel.
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t xreg[UP ? 1 : NX], greg[UP ? 1 : NG];
+#define GW_LOADREG(TILE)                                                                                      \
+    {                                                                                                         \
+        int tt_ = (TILE);                                                                                     \
+        const int tx_ = tt_ % p.tiles_x; tt_ /= p.tiles_x;                                                    \
+        const int ty_ = tt_ % p.tiles_y, n_ = tt_ / p.tiles_y;                                                \
+        const int a0_ = ty_ * GW_TH, b0_ = tx_ * GW_TW;                                                       \
+        const __amdgpu_buffer_rsrc_t xr_ = GW_RSRC(p.src.ptr + (size_t)n_ * p.Hv * p.Wv * p.src.cstride,       \
+                                                   (unsigned)(p.Hv * p.Wv * p.src.cstride) * 4u);             \
+        const unsigned xb_ = (unsigned)((((a0_ - 1) * p.Wv + b0_ - 1) * p.src.cstride + p.src.coff + ci0) * 4); \
+        const unsigned xlo_ = b0_ == 0, xn_ = min(GW_HPW, p.Wv - b0_ + 1) - xlo_;                             \
+        const unsigned jn_ = (unsigned)((p.src.C - ci0 + 3) >> 2);                                            \
+        const bool xin_ = xn_ == (unsigned)GW_HPW && jn_ >= (unsigned)CI4;                                    \
+        _Pragma("unroll") for (int it_ = 0; it_ < NX; ++it_) {                                                \
+            const unsigned id_ = it_ * 256 + tid, pix_ = id_ / CI4, j_ = id_ % CI4;                           \
+            const unsigned hx_ = pix_ - ((pix_ * 3641u) >> 16) * GW_HPW;                                      \
+            const bool ok_ = xin_ || (hx_ - xlo_ < xn_ && j_ < jn_);                                          \
+            xreg[it_] = __builtin_amdgcn_raw_buffer_load_b128(xr_, ok_ ? xb_ + xoff[it_] : 0x80000000u, 0, 0); \
+        }                                                                                                     \
+        const __amdgpu_buffer_rsrc_t gr_ = GW_RSRC(p.g + (size_t)n_ * p.Ho * p.Wo * p.g_cstride,              \
+                                                   (unsigned)(p.Ho * p.Wo * p.g_cstride) * 4u);               \
+        const unsigned gb_ = (unsigned)(((a0_ * p.Wo + b0_) * p.g_cstride + p.g_coff + co0) * 4);              \
+        const unsigned gxn_ = min(GW_TW, p.Wo - b0_);                                                         \
+        const unsigned gjn_ = (unsigned)((((p.Cout + 3) & ~3) - co0 + 3) >> 2);                               \
+        const bool gin_ = gxn_ == (unsigned)GW_TW && gjn_ >= (unsigned)CO4;                                   \
+        _Pragma("unroll") for (int it_ = 0; it_ < NG; ++it_) {                                                \
+            const unsigned id_ = it_ * 256 + tid, gx_ = (id_ / CO4) % GW_TW, j_ = id_ % CO4;                  \
+            const bool ok_ = gin_ || (gx_ < gxn_ && j_ < gjn_);                                               \
+            greg[it_] = __builtin_amdgcn_raw_buffer_load_b128(gr_, ok_ ? gb_ + goff[it_] : 0x80000000u, 0, 0); \
+        }                                                                                                     \
+    }
+#define GW_STOREREG(BUF)                                                                                      \
+    {                                                                                                         \
+        _Pragma("unroll") for (int it_ = 0; it_ < NX; ++it_)                                                  \
+            if (NX * 256 == GW_HPH * GW_HPW * CI4 || it_ * 256 + tid < GW_HPH * GW_HPW * CI4)                 \
+                *((u32x4_t*)(Xs0 + (BUF) * XSZ) + it_ * 256 + tid) = xreg[it_];                               \
+        _Pragma("unroll") for (int it_ = 0; it_ < NG; ++it_) *((u32x4_t*)(Gs0 + (BUF) * GSZ) + it_ * 256 + tid) = greg[it_]; \
+    }
     if (tile_beg < tile_end) GW_STAGE(tile_beg, 0)
     int buf = 0;
     for (int tile = tile_beg; tile < tile_end; ++tile, buf ^= 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                   // this tile has landed; every wave is done with the other buffer
-        if (tile + 1 < tile_end) GW_STAGE(tile + 1, buf ^ 1)
+        if (tile + 1 < tile_end) {
+            if (UP || !SSIE_WGW_REGSTAGE) GW_STAGE(tile + 1, buf ^ 1)
+            else GW_LOADREG(tile + 1)
+        }
         const float* Xs = Xs0 + buf * XSZ;
         const float* Gs = Gs0 + buf * GSZ;
         if (do_bias)
@@ -230,7 +279,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int u = 0; u < 16; ++u) acc[u] = MFMA32(V[u].y, H[u].y, acc[u]);
         }
+        if (!UP && SSIE_WGW_REGSTAGE && tile + 1 < tile_end) GW_STOREREG(buf ^ 1)
     }
+#undef GW_LOADREG
+#undef GW_STOREREG
 #undef GW_STAGE
 #undef GW_RSRC
 #undef GW_BLDS
