@@ -14,6 +14,7 @@
 // staged per tap group.  K is permuted inside each chunk so that one ds_read_b128 feeds four
 // consecutive MFMAs: lane (i, h) holds channels 8*kq + 4*h + {0..3}.
 #include "conv_device.h"
+#include <string.h>
 
 // Diagnostic build only (-DSSIE_STAMP, tools/stamp_conv.py): per-workgroup s_memtime stamps of the fprop phases,
 // written to a buffer of their own.  The shipped library never executes a stamp.
@@ -588,28 +589,25 @@ template __global__ void conv_wgrad_kernel<32, 64, 9, 4>(const WgradParams);
 // per thread run the same bytes in half the time.  (The slice reduction is NOT hidden by the side stream any more: SSIE_OVERLAP=0
 // and 1 time the same since the persistent convolution kernels leave it no CU to overlap on - it is paid in full.)
 template <int OQ>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int nslices, int ntaps, int ci_pad, int co_pad,
-                                    int Cin, int Cout, float* __restrict__ dst, long s_co, long s_ci, long s_t,
-                                    const float* __restrict__ bias_slabs, float* __restrict__ db, int accumulate, int accumulate_bias,
-                                    int co_group, long w_extra, long b_extra)
+__device__ __forceinline__ void wgrad_reduce_body(const ReduceDesc& d, const long blk, f32x4* red)
 {
     // co_group > 0: the output channels are co_group-sized blocks of DIFFERENT parameter tensors (q | k | v): block j's weights sit
     // j * w_extra floats further than co * s_co says, its bias j * b_extra further than db + co
     constexpr int SG = 256 / OQ;
-    __shared__ f32x4 red[SG][OQ];
     const int lo = threadIdx.x % OQ, sg = threadIdx.x / OQ;
+    const int nslices = d.nslices, Cin = d.Cin, Cout = d.Cout, co_pad = d.co_pad;
     const int cq = (Cout + 3) / 4;                                 // channel quads per (tap, ci) row
-    const long idx = (long)blockIdx.x * OQ + lo;
-    const long total = (long)ntaps * Cin * cq;
-    const long total_b = total + (bias_slabs ? cq : 0);
+    const long idx = blk * OQ + lo;
+    const long total = (long)d.ntaps * Cin * cq;
+    const long total_b = total + (d.bias_slabs ? cq : 0);
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
     int co = 0, ci = 0, t = 0;
     bool is_w = false, is_b = false;
     if (idx < total) {
         is_w = true;
         co = (int)(idx % cq) * 4; ci = (int)((idx / cq) % Cin); t = (int)(idx / ((long)cq * Cin));
-        const size_t slab_sz = (size_t)ntaps * ci_pad * co_pad;
-        const float* sp = slabs + ((size_t)t * ci_pad + ci) * co_pad + co;
+        const size_t slab_sz = (size_t)d.ntaps * d.ci_pad * co_pad;
+        const float* sp = d.slabs + ((size_t)t * d.ci_pad + ci) * co_pad + co;
         // 8 independent loads in flight per thread (the slabs are 100+ KB apart: latency-, not bandwidth-bound otherwise)
         int s = sg;
         for (; s + 7 * SG < nslices; s += 8 * SG) {
@@ -622,25 +620,47 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     } else if (idx < total_b) {
         is_b = true;
         co = (int)(idx - total) * 4;
-        for (int s = sg; s < nslices; s += SG) sum += *(const f32x4*)(bias_slabs + (size_t)s * co_pad + co);
+        for (int s = sg; s < nslices; s += SG) sum += *(const f32x4*)(d.bias_slabs + (size_t)s * co_pad + co);
     }
-    red[sg][lo] = sum;
+    red[sg * OQ + lo] = sum;
     __syncthreads();
     if (sg == 0 && (is_w || is_b)) {
-        f32x4 tot = red[0][lo];
+        f32x4 tot = red[lo];
 #pragma unroll
-        for (int g = 1; g < SG; ++g) tot += red[g][lo];             // fixed order
+        for (int g = 1; g < SG; ++g) tot += red[g * OQ + lo];       // fixed order
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (co + k >= Cout) break;
-            const long blk = co_group ? (co + k) / co_group : 0;
-            float* d = is_w ? dst + (co + k) * s_co + ci * s_ci + t * s_t + blk * w_extra : db + co + k + blk * b_extra;
-            *d = (is_w ? accumulate : accumulate_bias) ? (*d + tot[k]) : tot[k];
+            const long blkc = d.co_group ? (co + k) / d.co_group : 0;
+            float* o = is_w ? d.dst + (co + k) * d.s_co + ci * d.s_ci + t * d.s_t + blkc * d.w_extra : d.db + co + k + blkc * d.b_extra;
+            *o = (is_w ? d.accumulate : d.accumulate_bias) ? (*o + tot[k]) : tot[k];
         }
     }
 }
-template __global__ void wgrad_reduce_kernel<64>(const float*, int, int, int, int, int, int, float*, long, long, long, const float*, float*, int, int, int, long, long);
-template __global__ void wgrad_reduce_kernel<16>(const float*, int, int, int, int, int, int, float*, long, long, long, const float*, float*, int, int, int, long, long);
+
+template <int OQ>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceDesc d)
+{
+    __shared__ f32x4 red[256];
+    wgrad_reduce_body<OQ>(d, blockIdx.x, red);
+}
+template __global__ void wgrad_reduce_kernel<64>(const ReduceDesc);
+template __global__ void wgrad_reduce_kernel<16>(const ReduceDesc);
+
+// every layer's reduction of one backward pass in ONE launch: the table sits in the kernel-argument segment, a workgroup finds its
+// layer with scalar compares over begin[] (no memory chain), then runs the same body - same per-element summation order as the
+// per-layer launches, hence bit-identical gradients (tests/test_plan_gpu.py).  23 launches of 5 - 22 us (ramp-dominated, ~1.5 TB/s)
+// become one that streams every slab of the step.
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const ReduceBatch b)
+{
+    __shared__ f32x4 red[256];
+    int j = 0;                                                     // begin[] past the last layer holds INT_MAX: 32 scalar compares on two wide loads
+#pragma unroll
+    for (int i = 1; i <= SSIE_REDUCE_BATCH; ++i) j += (int)blockIdx.x >= b.begin[i] ? 1 : 0;
+    const long blk = (long)blockIdx.x - b.begin[j];
+    if (b.d[j].wide) wgrad_reduce_body<16>(b.d[j], blk, red);
+    else wgrad_reduce_body<64>(b.d[j], blk, red);
+}
 
 // per-channel sums of G over all pixels (bias gradient of the transposed conv), two-stage & deterministic.
 // Stage 1: a thread owns one channel quad (float4) and every (256 / quads)-th pixel of the block's range, with four
@@ -989,20 +1009,44 @@ int ssie_launch_wgrad(const WgradParams& p, hipStream_t st)
 
 int ssie_wgrad_reduce_wide_min = 64;      // launches with at least this many slices: 16 output quads x 16 slice groups per block
 extern "C" void ssie_debug_set_wgrad_reduce_wide_min(int v) { ssie_wgrad_reduce_wide_min = v; }
+ReduceDesc ssie_make_reduce(const float* slabs, int nslices, int ntaps, int ci_pad, int co_pad, int Cin, int Cout, float* dst, long s_co, long s_ci,
+                            long s_t, const float* bias_slabs, float* db, int accumulate, int accumulate_bias, int co_group, long w_extra, long b_extra)
+{
+    ReduceDesc d; memset(&d, 0, sizeof(d));
+    d.slabs = slabs; d.dst = dst; d.bias_slabs = bias_slabs; d.db = db;
+    d.s_co = s_co; d.s_ci = s_ci; d.s_t = s_t; d.w_extra = w_extra; d.b_extra = b_extra;
+    d.nslices = nslices; d.ntaps = ntaps; d.ci_pad = ci_pad; d.co_pad = co_pad; d.Cin = Cin; d.Cout = Cout;
+    d.accumulate = accumulate; d.accumulate_bias = accumulate_bias < 0 ? accumulate : accumulate_bias; d.co_group = co_group;
+    d.wide = nslices >= ssie_wgrad_reduce_wide_min;
+    return d;
+}
+static long reduce_blocks(const ReduceDesc& d)
+{
+    const long cq = (d.Cout + 3) / 4;
+    const long total = (long)d.ntaps * d.Cin * cq + (d.bias_slabs ? cq : 0);
+    return d.wide ? (total + 15) / 16 : (total + 63) / 64;
+}
 int ssie_launch_wgrad_reduce(const float* slabs, int nslices, int ntaps, int ci_pad, int co_pad, int Cin, int Cout,
                              float* dst, long s_co, long s_ci, long s_t, const float* bias_slabs, float* db,
                              int accumulate, hipStream_t st, int accumulate_bias, int co_group, long w_extra, long b_extra)
 {
-    const long cq = (Cout + 3) / 4;
-    long total = (long)ntaps * Cin * cq + (bias_slabs ? cq : 0);
-    if (nslices >= ssie_wgrad_reduce_wide_min)
-        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st,
-                           slabs, nslices, ntaps, ci_pad, co_pad, Cin, Cout, dst, s_co, s_ci, s_t, bias_slabs, db, accumulate,
-                           accumulate_bias < 0 ? accumulate : accumulate_bias, co_group, w_extra, b_extra);
-    else
-        hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st,
-                           slabs, nslices, ntaps, ci_pad, co_pad, Cin, Cout, dst, s_co, s_ci, s_t, bias_slabs, db, accumulate,
-                           accumulate_bias < 0 ? accumulate : accumulate_bias, co_group, w_extra, b_extra);
+    const ReduceDesc d = ssie_make_reduce(slabs, nslices, ntaps, ci_pad, co_pad, Cin, Cout, dst, s_co, s_ci, s_t, bias_slabs, db, accumulate,
+                                          accumulate_bias, co_group, w_extra, b_extra);
+    if (d.wide) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)reduce_blocks(d)), dim3(256), 0, st, d);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3((unsigned)reduce_blocks(d)), dim3(256), 0, st, d);
+    return hipGetLastError() == hipSuccess ? 0 : 25;
+}
+
+int ssie_launch_wgrad_reduce_batched(const ReduceDesc* d, int n, hipStream_t st)
+{
+    if (n < 1 || n > SSIE_REDUCE_BATCH) return 25;
+    ReduceBatch b; memset(&b, 0, sizeof(b));
+    b.n = n;
+    long at = 0;
+    for (int j = 0; j < n; ++j) { b.begin[j] = (int)at; b.d[j] = d[j]; at += reduce_blocks(d[j]); }
+    if (at >= 0x7fffffffL) return 25;
+    for (int j = n; j <= SSIE_REDUCE_BATCH; ++j) b.begin[j] = 0x7fffffff;
+    hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3((unsigned)at), dim3(256), 0, st, b);
     return hipGetLastError() == hipSuccess ? 0 : 25;
 }
 

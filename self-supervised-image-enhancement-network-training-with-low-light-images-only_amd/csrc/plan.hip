@@ -54,7 +54,7 @@ struct Plan {
     size_t nparam_floats = 0;
     std::map<std::string, BufInfo> bufs;
     size_t ws_floats = 0;
-    size_t slab_off = 0, slab_off2 = 0, slab_cap = 0, partial_off = 0, packdesc_off = 0, mask_off = 0, scal_off = 0;
+    size_t partial_off = 0, packdesc_off = 0, mask_off = 0, scal_off = 0;
     size_t lpart_off = 0, fpart_off = 0, counter_off = 0, fftws_off = 0, tailw_off = 0, skinny_off = 0;
     // frequency-domain 9 x 9 convolution (spectral_conv.hip): tiles per pass, padded band count, buffers (float offsets)
     bool spectral = false; int sp_Mt = 0, sp_Kp = 0, sp_slices = 2;      // 544 frequencies x 2 slices = 1 088 reduction workgroups
@@ -65,7 +65,7 @@ struct Plan {
     // bound state
     float* ws = nullptr; float* P = nullptr; float* G = nullptr;
     std::vector<PackDesc> packs;
-    size_t pack_cursor = 0, pack_floats_total = 0, pack_off = 0;
+    size_t pack_cursor = 0, pack_floats_total = 0, pack_off = 0, pack_cap = 0;    // pack_cap: what the dry build reserved (packed weights + slab regions)
     std::vector<Fn> fwd, pass2, lossbwd;
     std::vector<Fn> fwd16;       // enhance-only forward with bf16 storage / bf16 MFMA (ssie_plan_enhance_fwd_bf16)
     std::vector<Fn> fwdi;        // enhance-only forward in fp32: `fwd` with its last three launches replaced by the fused tail
@@ -178,11 +178,7 @@ void build_buffers(Plan& pl)
     // bf16 inference path: bf16 copies of the tensors that also exist in fp32 (allocated in float units: C/2)
     alloc(pl, "xh", N, H, W, ssie_round_up(B, 8) / 2); alloc(pl, "RLh", N, H, W, ssie_round_up(B + 1, 8) / 2); alloc(pl, "aoh", N, H8, W8, 32);
     // scratch
-    // one slab area: kWgs slices of a 9-tap group over a 64 x 64 block (the Winograd weight gradient writes kWgs / 2 slices of nine
-    // taps) + the per-layer remainder of the 9 x 9 / B+1-channel layers + the fused bias slabs
-    pl.slab_cap = (size_t)kWgs * 9 * 64 * 64 + (size_t)81 * ssie_round_up(B + 1, 64) * 128 + (size_t)kWgs * ssie_round_up(B + 1, 64);
-    pl.slab_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + pl.slab_cap, 64);
-    pl.slab_off2 = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + pl.slab_cap, 64);
+    // (the weight-gradient slab regions follow the packed weights: one per launch, sized by the dry build - Builder::take_slabs)
     pl.partial_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 256 * 256, 64);
     pl.loss_blocks = 2048; pl.fft_blocks = ssie_fft_partials(N, B, H, W);
     pl.lpart_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + (size_t)pl.loss_blocks * 8, 64);
@@ -209,6 +205,8 @@ void build_buffers(Plan& pl)
 }
 
 // -------------------------------------------------------------------------------------------------
+extern int g_overlap, g_batched_reduce;
+
 struct Builder {
     Plan& pl;
     bool dry;                 // dry run: only count packed-weight floats
@@ -396,25 +394,24 @@ struct Builder {
     int wgrad(std::vector<Fn>& ops, const LayerP& L, int stride, SrcDesc x, int creal, int Hv, int Wv, int ci_off, const char* g,
               int g_coff = 0, bool with_bias = false, int nbatch = 1, int co_group = 0, long w_extra = 0, long b_extra = 0)
     {
-        if (dry) return 0;
         const int T = L.k * L.k, pad = (L.k - 1) / 2;
         const BufInfo& gb = pl.bi(g);
         const int Ho = (Hv + 2 * pad - L.k) / stride + 1, Wo = (Wv + 2 * pad - L.k) / stride + 1;
         if (Ho != gb.H || Wo != gb.W) return SSIE_E_SHAPE;
         TapList t = ssie_taps_conv(L.k);
         WgradParams p;
-        const int sl = pl.slab_seq++ & 1;
-        const size_t soff = sl ? pl.slab_off2 : pl.slab_off;
-        int rc = ssie_make_wgrad(p, x, pl.N * nbatch, Hv, Wv, 0, pl.buf(g), gb.cs, g_coff, L.cout, Ho, Wo, stride, t, pl.ws + soff, kWgs);
+        int rc = ssie_make_wgrad(p, x, pl.N * nbatch, Hv, Wv, 0, ptr(g), gb.cs, g_coff, L.cout, Ho, Wo, stride, t, nullptr, kWgs);
         if (rc) return rc;
         const size_t need = ssie_wgrad_slab_floats(p);
         const size_t bneed = with_bias ? (size_t)p.nslices * p.co_pad : 0;
-        if (need + bneed > pl.slab_cap) return SSIE_E_WORKSPACE;     // before any op of this layer is pushed
+        float* slabs = take_slabs(need + bneed);                     // this launch's own region (the dry run sizes it)
+        if (dry) return 0;
+        p.slabs = slabs;
+        const int sl = pl.slab_seq++ & 1;
         float* dw = pl.G + L.w + (size_t)ci_off * T;
         const long s_co = (long)L.cin * T;
-        const float* slabs = pl.ws + soff;
         const int cout = L.cout;
-        float* bslab = with_bias ? pl.ws + soff + need : nullptr;
+        float* bslab = with_bias ? slabs + need : nullptr;
         float* db = with_bias ? pl.G + L.b : nullptr;
         p.bias_slabs = bslab;
         const double fl = 2.0 * pl.N * nbatch * Ho * Wo * (double)cout * creal * T;
@@ -425,9 +422,38 @@ struct Builder {
             const double hs = x.Hs < Hv ? x.Hs : Hv, ws = x.Ws < Wv ? x.Ws : Wv;
             ops.back().bytes = 4.0 * ((double)pl.N * nbatch * (hs * ws * creal + (double)Ho * Wo * cout) + (double)need + (double)bneed);
         }
-        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, p.nslices, p.ntaps, p.ci_pad, p.co_pad, creal, cout, dw, s_co, T, 1, bslab, db, 1, st, -1, co_group, w_extra, b_extra); }, K_WGRAD_REDUCE, 0.0, "", sl, SLAB_READ));
-        ops.back().bytes = 4.0 * ((double)need + (double)bneed + 2.0 * (double)creal * cout * T);   // ... and read once by the reduction (dW read-modify-write)
+        // ... and read once by the reduction (dW read-modify-write)
+        reduce(ops, ssie_make_reduce(slabs, p.nslices, p.ntaps, p.ci_pad, p.co_pad, creal, cout, dw, s_co, T, 1, bslab, db, 1, -1, co_group, w_extra, b_extra),
+               4.0 * ((double)need + (double)bneed + 2.0 * (double)creal * cout * T), sl);
         return 0;
+    }
+
+    // Each weight-gradient launch owns its slab region (sized by the dry run, behind the packed weights: ~0.3 GB at the 31-band
+    // configuration - nothing on 288 GB), so no reduction has to finish before a later launch may write: the reductions of one backward
+    // pass are collected and run as ONE batched launch at its end (flush_reduces; g_batched_reduce = 0 or the side-stream executor:
+    // one launch per layer right behind its producer, as before)
+    float* take_slabs(size_t floats) { return take_pack(floats); }
+    std::vector<ReduceDesc> pending;
+    double pending_bytes = 0.0;
+    void reduce(std::vector<Fn>& ops, const ReduceDesc& d, double bytes, int sl)
+    {
+        if (g_batched_reduce && !g_overlap) { pending.push_back(d); pending_bytes += bytes; return; }
+        ops.push_back(Fn([d](hipStream_t st) { return ssie_launch_wgrad_reduce(d.slabs, d.nslices, d.ntaps, d.ci_pad, d.co_pad, d.Cin, d.Cout, d.dst, d.s_co, d.s_ci, d.s_t,
+                                                                             d.bias_slabs, d.db, d.accumulate, st, d.accumulate_bias, d.co_group, d.w_extra, d.b_extra); },
+                         K_WGRAD_REDUCE, 0.0, "", sl, SLAB_READ));
+        ops.back().bytes = bytes;
+    }
+    void flush_reduces(std::vector<Fn>& ops)
+    {
+        for (size_t at = 0; at < pending.size(); at += SSIE_REDUCE_BATCH) {
+            const size_t n = pending.size() - at < SSIE_REDUCE_BATCH ? pending.size() - at : SSIE_REDUCE_BATCH;
+            std::vector<ReduceDesc> part(pending.begin() + at, pending.begin() + at + n);
+            char tag[64]; snprintf(tag, sizeof(tag), "batched reduction of %zu layers", n);
+            // slab = 2: reads every region; it runs in launch order behind all producers (no side stream in this mode)
+            ops.push_back(Fn([part](hipStream_t st) { return ssie_launch_wgrad_reduce_batched(part.data(), (int)part.size(), st); }, K_WGRAD_REDUCE, 0.0, tag, 2, SLAB_READ));
+            ops.back().bytes = pending_bytes * (double)n / (double)pending.size();
+        }
+        pending.clear(); pending_bytes = 0.0;
     }
 
     // q_linear | k_linear | v_linear (model.py:93-95, 104-106) as one 64 -> 192 1 x 1 layer into "qkv": three sub-block weight packs and
@@ -697,17 +723,22 @@ int build_decomposition_bwd(Builder& b, std::vector<Fn>& ops, const char* xin, i
     CK(b.dgrad(ops, L5, 1, G5.c_str(), 0, 0, 64, Gdc.c_str(), dc.c_str(), MASK_RELU, 0));
     CK(b.dgrad(ops, L5, 1, G5.c_str(), 0, 64, 64, G1.c_str(), c1.c_str(), MASK_RELU, 0));
     // ConvTranspose2d: wgrad with swapped roles, dgrad = stride-2 conv of Gdc with W read as OIHW (O = ci, I = co)
-    if (!b.dry && wg) {
+    if (wg) {
         SrcDesc gs = b.src("Gdc", 64, H, W);
         WgradParams wp; TapList t = ssie_taps_conv(3);
         const BufInfo& cb = pl.bi("c3_1");
-        const int sl = pl.slab_seq++ & 1;
-        const size_t soff = sl ? pl.slab_off2 : pl.slab_off;
-        CK(ssie_make_wgrad(wp, gs, pl.N * 2, H, W, 0, pl.buf("c3_1"), cb.cs, 0, 128, H2, W2, 2, t, pl.ws + soff, kWgs));
-        if (ssie_wgrad_slab_floats(wp) > pl.slab_cap) return SSIE_E_WORKSPACE;
-        float* dw = pl.G + Ld.w; const float* slabs = pl.ws + soff;
-        ops.push_back(Fn([wp](hipStream_t st) { return ssie_launch_wgrad(wp, st); }, K_WGRAD, 2.0 * pl.N * 2 * H2 * W2 * 128.0 * 64 * 9, "", sl, SLAB_WRITE));
-        ops.push_back(Fn([=](hipStream_t st) { return ssie_launch_wgrad_reduce(slabs, wp.nslices, wp.ntaps, wp.ci_pad, wp.co_pad, 64, 128, dw, 64L * 9, 9, 1, nullptr, nullptr, 1, st); }, K_WGRAD_REDUCE, 0.0, "", sl, SLAB_READ));
+        CK(ssie_make_wgrad(wp, gs, pl.N * 2, H, W, 0, b.ptr("c3_1"), cb.cs, 0, 128, H2, W2, 2, t, nullptr, kWgs));
+        const size_t need = ssie_wgrad_slab_floats(wp);
+        float* slabs = b.take_slabs(need);
+        if (!b.dry) {
+            wp.slabs = slabs;
+            const int sl = pl.slab_seq++ & 1;
+            float* dw = pl.G + Ld.w;
+            ops.push_back(Fn([wp](hipStream_t st) { return ssie_launch_wgrad(wp, st); }, K_WGRAD, 2.0 * pl.N * 2 * H2 * W2 * 128.0 * 64 * 9, "", sl, SLAB_WRITE));
+            ops.back().bytes = 4.0 * ((double)pl.N * 2 * ((double)H * W * 64 + (double)H2 * W2 * 128) + (double)need);
+            b.reduce(ops, ssie_make_reduce(slabs, wp.nslices, wp.ntaps, wp.ci_pad, wp.co_pad, 64, 128, dw, 64L * 9, 9, 1, nullptr, nullptr, 1),
+                     4.0 * ((double)need + 2.0 * 64 * 128 * 9), sl);
+        }
     }
     if (wg) b.bias_grad(ops, Ld, "Gdc", 0, 2);
     {
@@ -889,6 +920,7 @@ int build_all(Plan& pl, bool dry)
     CK(build_illum_bwd(b, ops));
     b.mask_axpy(ops, "gRL", "RL_1", MASK_SIGMOID, "G8", pl.B + 1, 0);
     CK(build_decomposition_bwd(b, ops, "x", 1, false));
+    b.flush_reduces(ops);          // nothing in this list reads a weight gradient: Adam / the all-reduce follow the whole list
     // bf16 inference list (its packs follow the fp32 ones)
     pl.npacks_train = pl.packs.size();
     pl.fwd16.clear();
@@ -908,6 +940,8 @@ int build_all(Plan& pl, bool dry)
         push_tail(b, pl.fwdi);
     }
     pl.pack_floats_total = pl.pack_cursor;
+    // a debug switch flipped between create and bind can change slice counts: refuse rather than write past the reservation
+    if (!dry && pl.pack_cap && pl.pack_cursor > pl.pack_cap) return SSIE_E_WORKSPACE;
     CK(check_slab_flags(pl.lossbwd));
     return 0;
 }
@@ -923,6 +957,7 @@ int g_fused_tail = 1;   // ssie_debug_set_fused_tail: 0 = inference runs feature
 int g_overlap = 0;      // ssie_debug_set_overlap: 1 = the weight gradients' slab reductions on a side stream (run_ops_overlapped).  Default 0
                         // since round 3: the persistent convolution kernels leave a side stream no CU to overlap on, and with the wider
                         // reduction kernel launch order on one stream is 0.07 ms per step FASTER at 31 bands (equal at 256)
+int g_batched_reduce = 1;   // ssie_debug_set_batched_reduce: 0 = one slab reduction per layer, right behind its weight-gradient launch (plans built afterwards)
 
 // backward schedule with the slab reductions on the side stream:
 //   wgrad(slab b)   on st   : waits for the reduction that last read slab b, then records ev_w[b]
@@ -949,6 +984,10 @@ int run_ops_overlapped(Plan& pl, std::vector<Fn>& ops, hipStream_t st)
             if (pending[f.slab]) { if (!ok(hipStreamWaitEvent(st, pl.ev_r[f.slab], 0))) break; pending[f.slab] = false; }
             if (f(st)) { rc = SSIE_E_LAUNCH; break; }
             if (!ok(hipEventRecord(pl.ev_w[f.slab], st))) break;
+        } else if (f.slab_use == SLAB_READ && f.slab == 2) {
+            // a batched reduction (list built for the other executor): every producer ran on st, so launch order is the dependency
+            for (int i = 0; i < 2; ++i) if (pending[i]) { if (!ok(hipStreamWaitEvent(st, pl.ev_r[i], 0))) break; pending[i] = false; }
+            if (rc || f(st)) { rc = SSIE_E_LAUNCH; break; }
         } else if (f.slab_use == SLAB_READ) {
             if (!ok(hipStreamWaitEvent(pl.side, pl.ev_w[f.slab], 0))) break;
             if (f(pl.side)) { rc = SSIE_E_LAUNCH; break; }
@@ -972,7 +1011,7 @@ int check_slab_flags(const std::vector<Fn>& ops)
     for (auto& f : ops) {
         const bool w = f.kind == K_WGRAD || f.kind == K_WGRAD_WINO, r = f.kind == K_WGRAD_REDUCE;
         if ((w && f.slab_use != SLAB_WRITE) || (r && f.slab_use != SLAB_READ) || (!w && !r && f.slab_use != SLAB_NONE)) return SSIE_E_ARG;
-        if (f.slab < 0 || f.slab > 1) return SSIE_E_ARG;
+        if (f.slab < 0 || f.slab > 2 || (f.slab == 2 && f.slab_use != SLAB_READ)) return SSIE_E_ARG;
     }
     return 0;
 }
@@ -1002,11 +1041,13 @@ extern "C" void* ssie_plan_create(int N, int bands, int H, int W, const float* c
     BufInfo t2 = t; t2.H = pl->H2; t2.W = pl->W2; pl->bufs["tmpH2"] = t2;
     BufInfo t4 = t; t4.H = pl->H4; t4.W = pl->W4; pl->bufs["tmpH4"] = t4;
     if (build_all(*pl, true)) { delete pl; return nullptr; }
+    pl->pack_cap = pl->pack_floats_total;
     pl->ws_floats = align_up(pl->pack_off + pl->pack_floats_total + 64, 64);
     return pl;
 }
 
 extern "C" void ssie_debug_set_overlap(int on) { g_overlap = on; }
+extern "C" void ssie_debug_set_batched_reduce(int on) { g_batched_reduce = on; }
 extern "C" void ssie_debug_set_graph(int on) { g_graph = on; }
 // product API (include/ssie_hip.h): replay this plan's train step as one hipGraph from its second call on (the first call runs every
 // launcher's one-time hipFuncSetAttribute; capture and the first replay happen at the second)

@@ -144,6 +144,20 @@ int ssie_launch_wgrad(const WgradParams& p, hipStream_t st);
 int ssie_launch_wgrad_reduce(const float* slabs, int nslices, int ntaps, int ci_pad, int co_pad, int Cin, int Cout,
                              float* dst, long s_co, long s_ci, long s_t, const float* bias_slabs, float* db,
                              int accumulate, hipStream_t st, int accumulate_bias = -1, int co_group = 0, long w_extra = 0, long b_extra = 0);
+// one layer's slab reduction as data: the batched launch (conv_kernels.hip) runs up to SSIE_REDUCE_BATCH of them, the table passed BY VALUE
+// in the kernel-argument segment (scalar loads, no device-side table to keep in step with the op list)
+struct ReduceDesc {
+    const float* slabs; float* dst; const float* bias_slabs; float* db;
+    long s_co, s_ci, s_t, w_extra, b_extra;
+    int nslices, ntaps, ci_pad, co_pad, Cin, Cout, accumulate, accumulate_bias, co_group, wide;
+};
+#define SSIE_REDUCE_BATCH 32
+struct ReduceBatch { int n; int begin[SSIE_REDUCE_BATCH + 1]; ReduceDesc d[SSIE_REDUCE_BATCH]; };     // begin[j] = first workgroup of layer j
+static_assert(sizeof(ReduceBatch) <= 4096, "the kernel-argument segment holds 4 KB");
+ReduceDesc ssie_make_reduce(const float* slabs, int nslices, int ntaps, int ci_pad, int co_pad, int Cin, int Cout, float* dst, long s_co, long s_ci,
+                            long s_t, const float* bias_slabs, float* db, int accumulate, int accumulate_bias = -1, int co_group = 0,
+                            long w_extra = 0, long b_extra = 0);
+int ssie_launch_wgrad_reduce_batched(const ReduceDesc* d, int n, hipStream_t st);      // n <= SSIE_REDUCE_BATCH, disjoint destinations
 int ssie_launch_wgrad_wino(const WgradParams& p, hipStream_t st);                      // conv_wgrad_wino.hip
 int ssie_launch_colsum(const float* g, long npix, int cstride, int coff, int C, float* partial, int nblk,
                        float* dst, int accumulate, hipStream_t st);

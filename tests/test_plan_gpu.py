@@ -129,7 +129,7 @@ def test_stagewise_parity(pkg, case, forced_kernels):
     def chk(label, got, ref, tol, kind="abs"):
         got = got.detach().double().cpu(); ref = ref.detach().double()
         err = (got - ref).abs().max().item() if kind == "abs" else rel_l2(got, ref)
-        report.append(f"{label:34s} {kind} {err:.3e} (tol {tol:.0e})")
+        report.append(f"{label:34s} {kind} {err:.3e} (tol {tol:.3e})")
         if not (err <= tol):
             bad.append(report[-1])
 
@@ -160,11 +160,16 @@ def test_stagewise_parity(pkg, case, forced_kernels):
     # intermediate gradients (state at the END of the step = pass-1 backward)
     inter = [("gS", "S", B), ("gD", "D", 1), ("G8", "c8_1", B + 1), ("G7", "c7_1", 64), ("Gsh", "sh_1", 64),
              ("Gf", "f", 64), ("gd3", "a0", 64)]
+    # The cotangents ARE the flip noise: which signs flip differs between any two fp32 forwards, and ONE fp32 oracle run is a noisy
+    # estimate of a tensor's own share of it - b4_160x288's d/dS measured 6.665e-3 against 2 x 3.311e-3 (2.01 x, identical bits with
+    # every executor / reduction mode, so not a kernel difference).  Same rule as the q/k gradients below: never tighter than 0.3 x the
+    # d/dD deviation of the fp32 oracle (2.87e-2 here: d/dS is 0.23 x).  The noise-free pins are tests/test_backward_gpu.py (2e-5).
+    ctol = lambda r32, r64: max(gtol(r32, r64), 0.3 * noise_D)
     for buf, key, c in inter:
-        chk("d/d " + key + " [" + buf + "]", plan.nchw(buf, 0, c), tr[key].grad, gtol(tr32[key].grad, tr[key].grad), "rel")
+        chk("d/d " + key + " [" + buf + "]", plan.nchw(buf, 0, c), tr[key].grad, ctol(tr32[key].grad, tr[key].grad), "rel")
     gRI = torch.cat([tr["R"].grad, tr["I"].grad], 1)
     gRI32 = torch.cat([tr32["R"].grad, tr32["I"].grad], 1)
-    chk("d/d (R,I) [gRL]", plan.nchw("gRL", 0, B + 1), gRI, gtol(gRI32, gRI), "rel")
+    chk("d/d (R,I) [gRL]", plan.nchw("gRL", 0, B + 1), gRI, ctol(gRI32, gRI), "rel")
 
     for name, off, shape in table:
         if name.endswith("k_linear.bias"):
@@ -203,6 +208,32 @@ def test_side_stream_overlap_is_bit_identical(pkg):
         L.ssie_debug_set_overlap(0)
     assert torch.equal(out[0][0], out[1][0])
     assert torch.equal(out[0][1], out[1][1])
+
+
+def test_batched_slab_reduction_is_bit_identical(pkg):
+    """Default: every weight-gradient slab reduction of a backward pass in ONE launch at its end (each producer owns its slab region);
+    ssie_debug_set_batched_reduce(0): one launch per layer right behind its producer.  Same body, same per-element summation order:
+    identical bits, and the batched list must be the shorter one by (layers - 1) launches."""
+    H, _ = pkg
+    L = H.lib()
+    n, bands, h, w, coefs = 2, 31, 64, 64, O.JYU_COEFS
+    x = O.synthetic_patches(n, bands, h, w).cuda()
+    out, launches = [], []
+    try:
+        for mode in (1, 0):
+            L.ssie_debug_set_batched_reduce(mode)
+            plan, table, flat, gflat, P = build_plan(H, n, bands, h, w, coefs)
+            for _ in range(2):
+                gflat.zero_()
+                plan.loss_fwd_bwd(x, backward=True)
+            torch.cuda.synchronize()
+            out.append((gflat.clone(), plan.loss_scalars().clone()))
+            launches.append(plan.profile_step(x)["wgrad_reduce_kernel"][2])
+    finally:
+        L.ssie_debug_set_batched_reduce(1)
+    assert torch.equal(out[0][0], out[1][0])
+    assert torch.equal(out[0][1], out[1][1])
+    assert launches[0] == 1 and launches[1] > 10, launches
 
 
 # Full small gradients vs the reference's fp32 values: two independent fp32 evaluations, each with its own sg() flips.  At 64 bands on
