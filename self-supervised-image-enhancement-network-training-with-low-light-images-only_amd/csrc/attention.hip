@@ -292,23 +292,34 @@ __global__ __launch_bounds__(256) void attn_kv_bf16_kernel(const float* __restri
 #define ATP_GLDS16(gptr, lptr)                                                                         \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),            \
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
-__global__ __launch_bounds__(256) void attn_fwd_bf16p_kernel(const float* __restrict__ qkv, int qs, const unsigned short* __restrict__ kg,
+// A workgroup = 128 queries of one head x TWO key halves: wave w = (query group w & 3, key half w >> 2) takes the 32-key blocks
+// 4 (w >> 2) .. + 3 of every staged 256-key slab and the two halves merge their (reference, sum, O) states through LDS at the end.
+// With one wave per 32 queries the image gave two waves per SIMD: too few to cover one wave's serial MFMA -> max -> vote -> exp ->
+// pack -> MFMA chain with another's; the key split makes it four.
+// The row sums come out of the second product: V^T has 16 real rows of the MFMA's 32, so the lanes of rows 16 - 31 feed ONES
+// (a constant LDS region addressed with the same immediates) and accumulator register 8 is sum_k P[k][query] - of the bf16-rounded
+// weights the numerator uses, over both lane halves; the 16 v_add_f32 per block and the cross-half exchange at the end go away.
+#define ATP_HB (AK_ST / 64)          // 32-key blocks per key half of a slab
+__global__ __launch_bounds__(512) void attn_fwd_bf16p_kernel(const float* __restrict__ qkv, int qs, const unsigned short* __restrict__ kg,
                                                              const unsigned short* __restrict__ vg, unsigned short* __restrict__ o, int os,
                                                              int T, int Tpad, float scale)
 {
     constexpr int KSL = AK_ST * 16, VSL = (AK_ST / 32) * 16 * AV_LD;         // ushorts per K / V slab: 8 KB and 10 KB
     __shared__ __attribute__((aligned(16))) unsigned short Kh[2][KSL];
     __shared__ __attribute__((aligned(16))) unsigned short Vt[2][VSL];
+    __shared__ __attribute__((aligned(16))) unsigned short Ones[ATP_HB * 16 * AV_LD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = wave & 3, kh = wave >> 2;
     const int h = lane >> 5, li = lane & 31;
     const int head = blockIdx.y, n = blockIdx.z;
-    const int qi = blockIdx.x * 128 + wave * 32 + li;
+    const int qi = blockIdx.x * 128 + wq * 32 + li;
     const float* base = qkv + (size_t)n * T * qs;
     const float LOG2E = 1.4426950408889634f;
     const unsigned short* kh_g = kg + ((size_t)n * 4 + head) * Tpad * 16;
     const unsigned short* vt_g = vg + ((size_t)n * 4 + head) * (Tpad / 32) * 16 * AV_LD;
 
+    for (int i = tid; i < ATP_HB * 16 * AV_LD / 2; i += 512) ((unsigned*)Ones)[i] = 0x3f803f80u;      // bf16 1.0 pairs (visible after the first barrier)
     uint4 qb;
     {
         f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0;
@@ -319,49 +330,48 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16p_kernel(const float* __rest
         const float c = scale * LOG2E;
         qb = make_uint4(at_pack2(q0[0] * c, q0[1] * c), at_pack2(q0[2] * c, q0[3] * c), at_pack2(q1[0] * c, q1[1] * c), at_pack2(q1[2] * c, q1[3] * c));
     }
-    f32x16 oacc;
+    f32x16 oacc;                 // [0..7]: O^T rows of this lane half; [8]: the row sum (rows 16 - 31 all hold it)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
-    // minus the reference of the logits (see the loop); the first block sets it
+    // minus the reference of the logits (see the loop); this wave's first block sets it
     f32x16 negm;
 #pragma unroll
     for (int r = 0; r < 16; ++r) negm[r] = 0.f;
-    float lsum = 0.f;
 
-    // one slab = 8 K pieces + 10 V pieces of 1 KB (64 lanes x 16 B): wave w takes K pieces 2w, 2w + 1 and V pieces w, w + 4 (, w + 8)
+    // one slab = 8 K pieces + 10 V pieces of 1 KB (64 lanes x 16 B): wave w takes K piece w and V pieces w (, w + 8)
 #define ATP_STAGE(SLAB, BUF)                                                                                          \
     {                                                                                                                 \
         const unsigned short* ks_ = kh_g + (size_t)(SLAB) * KSL;                                                      \
         const unsigned short* vs_ = vt_g + (size_t)(SLAB) * VSL;                                                      \
-        _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_)                                                              \
-            ATP_GLDS16(ks_ + (2 * wave + q_) * 512 + lane * 8, &Kh[BUF][(2 * wave + q_) * 512]);                      \
-        _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_)                                                              \
-            if (wave + 4 * q_ < VSL / 512) ATP_GLDS16(vs_ + (wave + 4 * q_) * 512 + lane * 8, &Vt[BUF][(wave + 4 * q_) * 512]); \
+        ATP_GLDS16(ks_ + wave * 512 + lane * 8, &Kh[BUF][wave * 512]);                                                \
+        ATP_GLDS16(vs_ + wave * 512 + lane * 8, &Vt[BUF][wave * 512]);                                                \
+        if (wave + 8 < VSL / 512) ATP_GLDS16(vs_ + (wave + 8) * 512 + lane * 8, &Vt[BUF][(wave + 8) * 512]);          \
     }
     const int nslab = Tpad / AK_ST;
     ATP_STAGE(0, 0)
     for (int s = 0; s < nslab; ++s) {
-        const int buf = s & 1, k0 = s * AK_ST;
+        const int buf = s & 1, kbase = s * AK_ST + kh * (AK_ST / 2);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (s + 1 < nslab) ATP_STAGE(s + 1, buf ^ 1)
-        const unsigned short* Kb = Kh[buf];
-        const unsigned short* Vb = Vt[buf];
-        // the logits of block sub + 1 are issued before the softmax of block sub: the MFMA -> max -> exp -> pack -> MFMA chain of
-        // one block is serial, and two waves per SIMD do not cover it
+        if (kbase >= T) continue;                                   // wave-uniform: this half of the last slab is padding
+        const unsigned short* Kb = Kh[buf] + kh * (AK_ST / 2) * 16;
+        // rows 16 - 31 of V^T: ones; the offsets added below are the same compile-time immediates for every lane
+        const unsigned short* Va = (li & 16) ? Ones + h * 8 : Vt[buf] + (kh * ATP_HB * 16 + (li & 15)) * AV_LD + h * 8;
+        // the logits of block i + 1 are issued before the softmax of block i: the MFMA -> max -> exp -> pack -> MFMA chain of
+        // one block is serial
         f32x16 stn = MFMA_BF16(*(const uint4*)(Kb + li * 16 + 8 * h), qb, negm);
 #pragma unroll
-        for (int sub = 0; sub < AK_ST / 32; ++sub) {
-            const int lr = sub * 32;
-            const int kb = k0 + lr;
+        for (int i = 0; i < ATP_HB; ++i) {
+            const int lr = i * 32;
+            const int kb = kbase + lr;
             if (kb >= T) break;
             // LAZY running maximum: the accumulator starts at -m (negm: 16 registers that only change on the slow path), so the
             // MFMA returns s - m directly, and the state is re-based only when a logit of this block exceeds the reference by
             // more than 2^8 (softmax is invariant to the reference; 2^8 is far inside fp32 / bf16 range).  After the first
-            // blocks that is rare, and the common path per block is: one MFMA, a max tree + one wave vote, 16 v_exp_f32, the row
-            // sum, 8 packed converts, two MFMAs - about half the vector instructions of the eager form, which is what bounds this
-            // kernel (head dimension 16: 3 MFMAs per 1 024 logits).
+            // blocks that is rare, and the common path per block is: one MFMA, a max tree + one wave vote, 16 v_exp_f32, 8 packed
+            // converts, two MFMAs - the vector instructions are what bounds this kernel (head dimension 16: 3 MFMAs per 1 024 logits).
             f32x16 st = stn;
-            if (sub + 1 < AK_ST / 32) stn = MFMA_BF16(*(const uint4*)(Kb + (lr + 32 + li) * 16 + 8 * h), qb, negm);
+            if (i + 1 < ATP_HB) stn = MFMA_BF16(*(const uint4*)(Kb + (lr + 32 + li) * 16 + 8 * h), qb, negm);
             if (kb + 32 > T) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
@@ -371,30 +381,24 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16p_kernel(const float* __rest
 #pragma unroll
             for (int r = 3; r < 15; r += 2) mb = fmaxf(fmaxf(mb, st[r]), st[r + 1]);
             mb = fmaxf(mb, st[15]);
-            const bool first = s == 0 && sub == 0;                  // the very first block sets the reference to its own maximum
+            const bool first = s == 0 && i == 0;                    // this wave's very first block sets the reference to its own maximum
             if (first || __builtin_amdgcn_ballot_w64(mb > 8.f)) {
                 // slow path (whole wave): both lane halves of a query share the reference
                 mb = fmaxf(mb, __shfl_xor(mb, 32));
                 const float d = first ? mb : fmaxf(mb, 0.f);        // afterwards the reference only ever rises
-                // the first block only moves the reference (lsum and oacc are still 0): no rescale - exp2(-d) is +inf when every logit
+                // the first block only moves the reference (the sums are still 0): no rescale - exp2(-d) is +inf when every logit
                 // of the first 32 keys sits below -128, and 0 * inf would leave that query NaN for good
                 const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-d);
-                lsum *= alpha;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) oacc[r] *= alpha;
+                for (int r = 0; r < 9; ++r) oacc[r] *= alpha;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { st[r] -= d; stn[r] -= d; negm[r] -= d; }          // (the prefetched block was formed against the old reference)
             }
-            float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                st[r] = __builtin_amdgcn_exp2f(st[r]); st[r + 1] = __builtin_amdgcn_exp2f(st[r + 1]);
-                ps0 += st[r]; ps1 += st[r + 1];
-            }
-            lsum += ps0 + ps1;
+            for (int r = 0; r < 16; ++r) st[r] = __builtin_amdgcn_exp2f(st[r]);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const uint4 va = *(const uint4*)(Vb + (sub * 16 + (li & 15)) * AV_LD + j * 16 + h * 8);
+                const uint4 va = *(const uint4*)(Va + (i * 16) * AV_LD + j * 16);
                 const uint4 pb = make_uint4(at_pack2(st[8 * j + 0], st[8 * j + 1]), at_pack2(st[8 * j + 2], st[8 * j + 3]),
                                             at_pack2(st[8 * j + 4], st[8 * j + 5]), at_pack2(st[8 * j + 6], st[8 * j + 7]));
                 oacc = MFMA_BF16(va, pb, oacc);
@@ -402,12 +406,30 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16p_kernel(const float* __rest
         }
     }
 #undef ATP_STAGE
-    lsum += __shfl_xor(lsum, 32);
-    if (qi < T) {
-        const float inv = 1.f / lsum;
+    // merge the two key halves (fixed order: half 0 + half 1).  A half without keys (a token count inside the first half slab)
+    // has sum 0 and takes the other's reference.
+    __syncthreads();
+    float* red = (float*)&Kh[0][0];                                  // 10 x 256 floats of the 16 KB the key slabs held
+    static_assert(10 * 256 * sizeof(float) <= sizeof(unsigned short) * 2 * KSL, "merge scratch does not fit the key slabs");
+    const int slot = wq * 64 + lane;
+    if (kh == 1) {
+        red[slot] = negm[0];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) red[(1 + r) * 256 + slot] = oacc[r];
+    }
+    __syncthreads();
+    if (kh == 0 && qi < T) {
+        const float l2 = red[9 * 256 + slot];
+        const float nm1 = negm[0], nm2 = l2 == 0.f ? nm1 : red[slot];
+        const float nmn = fminf(nm1, nm2);                          // minus the larger reference
+        const float a1 = __builtin_amdgcn_exp2f(nmn - nm1), a2 = __builtin_amdgcn_exp2f(nmn - nm2);
+        const float inv = 1.f / (oacc[8] * a1 + l2 * a2);
+        float ov[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ov[r] = (oacc[r] * a1 + red[(1 + r) * 256 + slot] * a2) * inv;
         unsigned short* op = o + ((size_t)n * T + qi) * os + head * AT_D + 4 * h;
-        *(uint2*)op = make_uint2(at_pack2(oacc[0] * inv, oacc[1] * inv), at_pack2(oacc[2] * inv, oacc[3] * inv));
-        *(uint2*)(op + 8) = make_uint2(at_pack2(oacc[4] * inv, oacc[5] * inv), at_pack2(oacc[6] * inv, oacc[7] * inv));
+        *(uint2*)op = make_uint2(at_pack2(ov[0], ov[1]), at_pack2(ov[2], ov[3]));
+        *(uint2*)(op + 8) = make_uint2(at_pack2(ov[4], ov[5]), at_pack2(ov[6], ov[7]));
     }
 }
 
@@ -598,7 +620,7 @@ int ssie_launch_attn_fwd_bf16(const float* qkv, int qs, void* o, int os, int N, 
         unsigned short* kg = (unsigned short*)scratch;
         unsigned short* vg = kg + (size_t)N * 4 * Tpad * 16;
         hipLaunchKernelGGL(attn_kv_bf16_kernel, dim3(Tpad / 64, N), dim3(256), 0, st, qkv, qs, kg, vg, T, Tpad);
-        hipLaunchKernelGGL(attn_fwd_bf16p_kernel, dim3((T + 127) / 128, 4, N), dim3(256), 0, st, qkv, qs, (const unsigned short*)kg,
+        hipLaunchKernelGGL(attn_fwd_bf16p_kernel, dim3((T + 127) / 128, 4, N), dim3(512), 0, st, qkv, qs, (const unsigned short*)kg,
                            (const unsigned short*)vg, (unsigned short*)o, os, T, Tpad, 0.25f);
         return hipGetLastError() == hipSuccess ? 0 : 64;
     }
