@@ -64,6 +64,7 @@ void ssie_fourier_mask_host(int H, int W, float cutoff, uint8_t* out);
 
 // fused inference tail (tail_kernels.hip): feature_fusion + final_conv + S = R*(I_delta + I_low) in one launch
 int ssie_tail_supported(int H, int W, int H2, int W2, int H4, int W4);
+size_t ssie_tail_weight_floats();     // floats of the composite-weight buffer (fp32 weights + the bf16 MFMA operand images)
 int ssie_launch_tail_weights(const float* wf, const float* bf, const float* wl, const float* bl, float* out, hipStream_t st);
 int ssie_launch_tail(const void* d1, const void* d2, const void* d3, int bf16_in, int N, int H, int W, int H2, int W2, int H4, int W4,
                      const float* wc, const float* RL, int rl_cs, float* D, int d_cs, float* S, int s_cs, int B, hipStream_t st);

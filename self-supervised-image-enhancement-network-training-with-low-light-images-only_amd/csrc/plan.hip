@@ -187,7 +187,7 @@ void build_buffers(Plan& pl)
     pl.fftws_floats = ssie_fft_workspace_floats(N, B, H, W);
     pl.fftws_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + pl.fftws_floats, 64);   // three-pass Fourier loss (band-grouped rows, or planes larger than the LDS)
     pl.mask_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + ((size_t)H * W + 3) / 4, 64);
-    pl.tailw_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + 3 * 9 * 64 + 16, 64);     // composite weights of the fused tail
+    pl.tailw_off = pl.ws_floats; pl.ws_floats = align_up(pl.ws_floats + ssie_tail_weight_floats(), 64);     // composite weights of the fused tail
     {   // spectral 9 x 9 (tile-major): X^ of both passes [2 Mt][f][Kp], Y^ / halo-G^ [Mt][f][64], Z^ [Mt][f][Kp], no-halo G^ [2 Mt][f][64], weights, dW^ slices
         int ty, tx; pl.sp_Mt = N * ssie_spec_tiles(H, W, &ty, &tx); pl.sp_Kp = pl.CX;
         pl.spectral = g_spectral9 && pl.CX % 32 == 0;

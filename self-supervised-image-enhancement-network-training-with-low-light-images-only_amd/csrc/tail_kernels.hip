@@ -13,6 +13,14 @@
 // band axis on the lanes.  Only the training forward keeps the two layers apart (their weight gradients need f).
 #include "loss_kernels.h"
 
+// Composite-weight buffer (floats): Wc [3][9][64] | cb [9] | b_final | pad to 1744 | the bf16 B-operand images of the MFMA phase:
+// uint4 index ((source * 2 + k-half) * 2 + hi/lo) * 64 + lane, lane (tap = lane & 15, k-group = lane >> 4) holding channels
+// 32 k-half + 8 k-group + 0..7 of its tap (taps 9 - 15: zero).  hi = bf16(w), lo = bf16(w - hi): two MFMAs per operand keep the
+// weights at ~16 mantissa bits (the fp32 tail multiplies fp32 weights), the activations are bf16 either way.
+#define TAILW_PACK_OFF 1744
+#define TAILW_FLOATS (TAILW_PACK_OFF + 3 * 2 * 2 * 64 * 4)
+size_t ssie_tail_weight_floats() { return TAILW_FLOATS; }
+
 namespace {
 const int TT = 16;                       // output tile edge
 const int R3 = TT + 2;                   // full-resolution pixels per tile edge incl. the 3x3 halo
@@ -47,23 +55,49 @@ __global__ void tail_weights_kernel(const float* __restrict__ wf, const float* _
         for (int j = 0; j < 64; ++j) a += wl[j * 9 + tap] * bf[j];
         out[i] = a;
     } else if (i == 3 * 9 * 64 + 9) out[i] = bl[0];
+    else if (i >= TAILW_PACK_OFF && i < TAILW_PACK_OFF + 3 * 2 * 64 * 8) {
+        // one element of the B-operand images: (source s, k-half kk, lane, e)
+        const int j0 = i - TAILW_PACK_OFF, e = j0 & 7, lane = (j0 >> 3) & 63, kk = (j0 >> 9) & 1, s = j0 >> 10;
+        const int tap = lane & 15, k = 32 * kk + 8 * (lane >> 4) + e;
+        float a = 0.f;
+        if (tap < 9)
+            for (int j = 0; j < 64; ++j) a += wl[j * 9 + tap] * wf[j * 192 + s * 64 + k];
+        const unsigned hi = ssie_f2bf(a);
+        const unsigned lo = ssie_f2bf(a - __uint_as_float(hi << 16));
+        unsigned short* img = (unsigned short*)(out + TAILW_PACK_OFF);
+        img[(((s * 2 + kk) * 2 + 0) * 64 + lane) * 8 + e] = (unsigned short)hi;
+        img[(((s * 2 + kk) * 2 + 1) * 64 + lane) * 8 + e] = (unsigned short)lo;
+    }
 }
 
 __device__ __forceinline__ int nearest_src(int v, float s, int n) { return min((int)floorf((float)v * s), n - 1); }
 
+// 8 consecutive channels of a pixel as they sit in memory (16 B bf16 / 32 B fp32); the conversion is a separate step so that
+// several pixels' loads can be in flight before the first one is used
+template <bool BF16> struct Raw8 { uint4 a, b; };
 template <bool BF16>
-__device__ __forceinline__ void load8(const void* base, size_t pix, int c8, float* v)
+__device__ __forceinline__ Raw8<BF16> load8_raw(const void* base, size_t pix, int c8)
+{
+    Raw8<BF16> r;
+    if (BF16) { r.a = *(const uint4*)((const unsigned short*)base + pix * 64 + c8); r.b = r.a; }
+    else { r.a = *(const uint4*)((const float*)base + pix * 64 + c8); r.b = *(const uint4*)((const float*)base + pix * 64 + c8 + 4); }
+    return r;
+}
+template <bool BF16>
+__device__ __forceinline__ void unpack8(const Raw8<BF16>& r, float* v)
 {
     if (BF16) {
-        const uint4 u = *(const uint4*)((const unsigned short*)base + pix * 64 + c8);
-        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+        const unsigned w[4] = {r.a.x, r.a.y, r.a.z, r.a.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
     } else {
-        const f32x4 a = *(const f32x4*)((const float*)base + pix * 64 + c8), b = *(const f32x4*)((const float*)base + pix * 64 + c8 + 4);
-        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+        v[0] = __uint_as_float(r.a.x); v[1] = __uint_as_float(r.a.y); v[2] = __uint_as_float(r.a.z); v[3] = __uint_as_float(r.a.w);
+        v[4] = __uint_as_float(r.b.x); v[5] = __uint_as_float(r.b.y); v[6] = __uint_as_float(r.b.z); v[7] = __uint_as_float(r.b.w);
     }
 }
+
+typedef __bf16 tail_bf16x8 __attribute__((ext_vector_type(8)));
+#define TAIL_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tail_bf16x8, (a)), __builtin_bit_cast(tail_bf16x8, (b)), (c), 0, 0, 0)
 
 template <bool BF16>
 __global__ __launch_bounds__(256) void tail_kernel(const TailParams p)
@@ -75,7 +109,7 @@ __global__ __launch_bounds__(256) void tail_kernel(const TailParams p)
     const int tiles_x = (p.W + TT - 1) / TT, tiles_y = (p.H + TT - 1) / TT;
     const int n = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x % (tiles_x * tiles_y);
     const int y0 = (tr / tiles_x) * TT, x0 = (tr % tiles_x) * TT;
-    for (int i = tid; i < 3 * 9 * 64 + 10; i += 256) wcs[i] = p.wc[i];
+    for (int i = tid + (BF16 ? 3 * 9 * 64 : 0); i < 3 * 9 * 64 + 10; i += 256) wcs[i] = p.wc[i];     // (bf16: only cb / b_final - the weights are MFMA operands)
     // source-pixel windows of the two coarse levels that the (clamped) full-resolution window maps to
     const int vy_lo = max(y0 - 1, 0), vy_hi = min(y0 + TT, p.H - 1), vx_lo = max(x0 - 1, 0), vx_hi = min(x0 + TT, p.W - 1);
     const int y2lo = nearest_src(vy_lo, p.sy2, p.H2), x2lo = nearest_src(vx_lo, p.sx2, p.W2);
@@ -89,6 +123,61 @@ __global__ __launch_bounds__(256) void tail_kernel(const TailParams p)
     // instead of being re-read from LDS for every pixel (18 ds_read_b128 per pixel and lane). ----
     const int sub = tid & 7, slot = tid >> 3;
     const int n3 = R3 * R3, n2 = n2y * n2x, n1 = n1y * n1x;
+    if (BF16) {
+        // bf16 sources: the nine dot products of 16 source pixels are two v_mfma_f32_16x16x32_bf16 (x 2 for the hi / lo weight split):
+        // A = the pixels' 64 channels straight from global memory (lane (pixel = lane & 15, k-group = lane >> 4): 16 bytes of its
+        // pixel), B = the weight images, D = lane (tap = lane & 15) holds pixels 4 (lane >> 4) + 0..3.  The VALU form below cost
+        // ~130 vector instructions per 8 pixels and wave (72 FMAs, 27 cross-lane adds): the kernel was VALU-bound at 2.3 TB/s.
+        const int wave = tid >> 6, lane = tid & 63, li = lane & 15, kg = lane >> 4;
+        const uint4* wimg = (const uint4*)(p.wc + TAILW_PACK_OFF);
+        constexpr int G = 6;                                        // 16-pixel groups per wave in flight (21 groups / 4 waves at full resolution)
+#pragma unroll 1
+        for (int lvl = 0; lvl < 3; ++lvl) {
+            const int items = lvl == 0 ? n1 : lvl == 1 ? n2 : n3;
+            const unsigned short* base = (const unsigned short*)(lvl == 0 ? p.d1 : lvl == 1 ? p.d2 : p.d3);
+            float* Tl = lvl == 0 ? T1 : lvl == 1 ? T2 : T3;
+            const uint4 bh0 = wimg[((lvl * 2 + 0) * 2 + 0) * 64 + lane], bl0 = wimg[((lvl * 2 + 0) * 2 + 1) * 64 + lane];
+            const uint4 bh1 = wimg[((lvl * 2 + 1) * 2 + 0) * 64 + lane], bl1 = wimg[((lvl * 2 + 1) * 2 + 1) * 64 + lane];
+            const int ngroups = (items + 15) >> 4;
+            for (int g0 = wave; g0 < ngroups; g0 += 4 * G) {
+                uint4 a0[G], a1[G];
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const int it = (g0 + 4 * u) * 16 + li;
+                    size_t pix = 0; bool inside = it < items;
+                    if (lvl == 2) {
+                        const int yy = y0 - 1 + it / R3, xx = x0 - 1 + it % R3;
+                        inside = inside && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+                        pix = ((size_t)n * p.H + yy) * p.W + xx;
+                    } else if (lvl == 1) {
+                        pix = ((size_t)n * p.H2 + y2lo + it / n2x) * p.W2 + x2lo + it % n2x;
+                    } else {
+                        pix = ((size_t)n * p.H4 + y1lo + it / n1x) * p.W4 + x1lo + it % n1x;
+                    }
+                    a0[u] = make_uint4(0u, 0u, 0u, 0u); a1[u] = a0[u];
+                    if (inside) {
+                        a0[u] = *(const uint4*)(base + pix * 64 + kg * 8);
+                        a1[u] = *(const uint4*)(base + pix * 64 + 32 + kg * 8);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const int g = g0 + 4 * u;
+                    if (g >= ngroups) break;                        // wave-uniform
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    acc = TAIL_MFMA(a0[u], bh0, acc); acc = TAIL_MFMA(a0[u], bl0, acc);
+                    acc = TAIL_MFMA(a1[u], bh1, acc); acc = TAIL_MFMA(a1[u], bl1, acc);
+                    if (li < 9) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int it = g * 16 + 4 * kg + r;
+                            if (it < items) Tl[it * 9 + li] = acc[r];
+                        }
+                    }
+                }
+            }
+        }
+    } else
 #pragma unroll 1
     for (int lvl = 0; lvl < 3; ++lvl) {
         const int items = lvl == 0 ? n1 : lvl == 1 ? n2 : n3;
@@ -100,32 +189,44 @@ __global__ __launch_bounds__(256) void tail_kernel(const TailParams p)
             const f32x4 wa = *(const f32x4*)(wcs + (lvl * 9 + t) * 64 + sub * 8), wb = *(const f32x4*)(wcs + (lvl * 9 + t) * 64 + sub * 8 + 4);
             wr[t][0] = wa[0]; wr[t][1] = wa[1]; wr[t][2] = wa[2]; wr[t][3] = wa[3]; wr[t][4] = wb[0]; wr[t][5] = wb[1]; wr[t][6] = wb[2]; wr[t][7] = wb[3];
         }
-        for (int it = slot; it < ((items + 31) & ~31); it += 32) {
-            float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (it < items) {
-                size_t pix; bool inside = true;
+        // FOUR pixels per lane and pass: their loads are issued together (one load in flight per lane made the 11 + 4 + 2 passes of
+        // a tile a chain of memory latencies - the kernel ran at 2.3 TB/s of 16-byte loads with the VALU idle)
+        constexpr int U = 4;
+        for (int it0 = slot; it0 < ((items + 31) & ~31); it0 += 32 * U) {
+            Raw8<BF16> raw[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int it = it0 + 32 * u;
+                size_t pix = 0; bool inside = it < items;
                 if (lvl == 2) {
                     const int yy = y0 - 1 + it / R3, xx = x0 - 1 + it % R3;
-                    inside = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+                    inside = inside && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
                     pix = ((size_t)n * p.H + yy) * p.W + xx;
                 } else if (lvl == 1) {
                     pix = ((size_t)n * p.H2 + y2lo + it / n2x) * p.W2 + x2lo + it % n2x;
                 } else {
                     pix = ((size_t)n * p.H4 + y1lo + it / n1x) * p.W4 + x1lo + it % n1x;
                 }
-                if (inside) {
-                    float v[8];
-                    load8<BF16>(base, pix, sub * 8, v);
-#pragma unroll
-                    for (int t = 0; t < 9; ++t)
-                        acc[t] = v[0] * wr[t][0] + v[1] * wr[t][1] + v[2] * wr[t][2] + v[3] * wr[t][3] + v[4] * wr[t][4] + v[5] * wr[t][5] + v[6] * wr[t][6] + v[7] * wr[t][7];
-                }
+                ok[u] = inside;
+                raw[u].a = make_uint4(0u, 0u, 0u, 0u); raw[u].b = raw[u].a;
+                if (inside) raw[u] = load8_raw<BF16>(base, pix, sub * 8);
             }
 #pragma unroll
-            for (int t = 0; t < 9; ++t) { float a = acc[t]; a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); acc[t] = a; }
-            if (it < items) {
+            for (int u = 0; u < U; ++u) {
+                const int it = it0 + 32 * u;
+                if (it >= ((items + 31) & ~31)) break;                 // whole groups of 32 slots leave together (the shuffles below)
+                float acc[9], v[8];
+                unpack8<BF16>(raw[u], v);                              // zeros outside the image / past the level's window
 #pragma unroll
-                for (int t = 0; t < 9; ++t) if (sub == (t & 7)) Tl[it * 9 + t] = acc[t];
+                for (int t = 0; t < 9; ++t)
+                    acc[t] = v[0] * wr[t][0] + v[1] * wr[t][1] + v[2] * wr[t][2] + v[3] * wr[t][3] + v[4] * wr[t][4] + v[5] * wr[t][5] + v[6] * wr[t][6] + v[7] * wr[t][7];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) { float a = acc[t]; a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); acc[t] = a; }
+                if (it < items) {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) if (sub == (t & 7)) Tl[it * 9 + t] = acc[t];
+                }
             }
         }
     }
@@ -137,14 +238,21 @@ __global__ __launch_bounds__(256) void tail_kernel(const TailParams p)
         float d = 0.f;
         if (y < p.H && x < p.W) {
             d = wcs[3 * 9 * 64 + 9];
+            // the three rows / columns of the 3 x 3 window in each level's table (nearest up-sampling resolved once per row / column)
+            int r3[3], c3[3], r2[3], c2[3], r1[3], c1[3]; bool rin[3], cin[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int qy = y + k - 1, qx = x + k - 1;
+                rin[k] = qy >= 0 && qy < p.H; cin[k] = qx >= 0 && qx < p.W;
+                const int cy = min(max(qy, 0), p.H - 1), cx = min(max(qx, 0), p.W - 1);
+                r3[k] = (qy - y0 + 1) * R3; c3[k] = qx - x0 + 1;
+                r2[k] = (nearest_src(cy, p.sy2, p.H2) - y2lo) * n2x; c2[k] = nearest_src(cx, p.sx2, p.W2) - x2lo;
+                r1[k] = (nearest_src(cy, p.sy4, p.H4) - y1lo) * n1x; c1[k] = nearest_src(cx, p.sx4, p.W4) - x1lo;
+            }
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const int qy = y + t / 3 - 1, qx = x + t % 3 - 1;
-                if (qy < 0 || qy >= p.H || qx < 0 || qx >= p.W) continue;           // zero padding of f (and of the gather)
-                const int i3 = (qy - y0 + 1) * R3 + (qx - x0 + 1);
-                const int i2 = (nearest_src(qy, p.sy2, p.H2) - y2lo) * n2x + (nearest_src(qx, p.sx2, p.W2) - x2lo);
-                const int i1 = (nearest_src(qy, p.sy4, p.H4) - y1lo) * n1x + (nearest_src(qx, p.sx4, p.W4) - x1lo);
-                d += wcs[3 * 9 * 64 + t] + T3[i3 * 9 + t] + T2[i2 * 9 + t] + T1[i1 * 9 + t];
+                if (!rin[t / 3] || !cin[t % 3]) continue;                                   // zero padding of f (and of the gather)
+                d += wcs[3 * 9 * 64 + t] + T3[(r3[t / 3] + c3[t % 3]) * 9 + t] + T2[(r2[t / 3] + c2[t % 3]) * 9 + t] + T1[(r1[t / 3] + c1[t % 3]) * 9 + t];
             }
             p.D[(((size_t)n * p.H + y) * p.W + x) * p.d_cs] = d;
         }
@@ -153,25 +261,38 @@ __global__ __launch_bounds__(256) void tail_kernel(const TailParams p)
     __syncthreads();
 
     // ---- phase 3: S = R * I_delta + R * I_low (model.py:233), four bands per lane ----
-    const int nq = p.s_cs >> 2;
-    for (int i = tid; i < TT * TT * nq; i += 256) {
-        const int px = i / nq, q = i - px * nq, y = y0 + (px >> 4), x = x0 + (px & 15);
-        if (y >= p.H || x >= p.W) continue;
-        const size_t pix = ((size_t)n * p.H + y) * p.W + x;
-        const float* rl = p.RL + pix * p.rl_cs;
-        const float dl = Dt[px], il = rl[p.B];
-        f32x4 r = {0.f, 0.f, 0.f, 0.f};
-        if (4 * q + 4 <= p.rl_cs) r = *(const f32x4*)(rl + 4 * q);
-        f32x4 s;
+    // (four pixel-quads per lane and pass, loads first: the load -> store -> load chain of a one-at-a-time loop is a latency chain too)
+    const int nq = p.s_cs >> 2, tot = TT * TT * nq;
+    constexpr int U3 = 4;
+    for (int i0 = tid; i0 < tot; i0 += 256 * U3) {
+        f32x4 r[U3]; float il[U3], dl[U3]; size_t pixs[U3]; int qs[U3]; bool ok[U3];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s[j] = (4 * q + j < p.B) ? r[j] * dl + r[j] * il : 0.f;
-        *(f32x4*)(p.S + pix * p.s_cs + 4 * q) = s;
+        for (int u = 0; u < U3; ++u) {
+            const int i = i0 + 256 * u;
+            const int px = i / nq, q = i - px * nq, y = y0 + (px >> 4), x = x0 + (px & 15);
+            ok[u] = i < tot && y < p.H && x < p.W;
+            pixs[u] = ((size_t)n * p.H + y) * p.W + x; qs[u] = q;
+            r[u] = f32x4{0.f, 0.f, 0.f, 0.f}; il[u] = 0.f; dl[u] = 0.f;
+            if (ok[u]) {
+                const float* rl = p.RL + pixs[u] * p.rl_cs;
+                il[u] = rl[p.B]; dl[u] = Dt[px];
+                if (4 * q + 4 <= p.rl_cs) r[u] = *(const f32x4*)(rl + 4 * q);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U3; ++u) {
+            if (!ok[u]) continue;
+            f32x4 sv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sv[j] = (4 * qs[u] + j < p.B) ? r[u][j] * dl[u] + r[u][j] * il[u] : 0.f;
+            *(f32x4*)(p.S + pixs[u] * p.s_cs + 4 * qs[u]) = sv;
+        }
     }
 }
 
 int ssie_launch_tail_weights(const float* wf, const float* bf, const float* wl, const float* bl, float* out, hipStream_t st)
 {
-    hipLaunchKernelGGL(tail_weights_kernel, dim3((3 * 9 * 64 + 10 + 255) / 256), dim3(256), 0, st, wf, bf, wl, bl, out);
+    hipLaunchKernelGGL(tail_weights_kernel, dim3((TAILW_PACK_OFF + 3 * 2 * 64 * 8 + 255) / 256), dim3(256), 0, st, wf, bf, wl, bl, out);
     return hipGetLastError() == hipSuccess ? 0 : 81;
 }
 
