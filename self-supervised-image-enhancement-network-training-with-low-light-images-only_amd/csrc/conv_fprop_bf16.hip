@@ -1172,6 +1172,8 @@ template __global__ void conv_fprop_bf16w_kernel<5, true, true>(const ConvParams
 #define INST_H(NT, NA2, TH) template __global__ void conv_fprop_bf16_kernel<NT, NA2, TH>(const ConvParams);
 INST_H(2, 3, 16) INST_H(2, 5, 16) INST_H(1, 3, 16) INST_H(1, 5, 16) INST_H(2, 5, 8)
 
+int ssie_bf16_two_wgs = 1;            // ssie_debug_set_bf16_two_wgs: 0 = one workgroup per CU for the 32-channel-tile kernel too
+extern "C" void ssie_debug_set_bf16_two_wgs(int v) { ssie_bf16_two_wgs = v; }
 static size_t lds_bytes_h(const ConvParams& p, int nt)
 {
     return 2 * ((size_t)p.hp_h * p.hp_w * 64 + (size_t)SSIE_TG * 4 * 32 * nt * 16) + (size_t)SSIE_MAX_TAPS * 4 + 16 + (size_t)p.Cout_pad * 8;
@@ -1183,7 +1185,11 @@ static int launch_h_t(const ConvParams& p, size_t lds, hipStream_t st)
     static unsigned seen = 0;
     ssie_allow_full_lds((const void*)conv_fprop_bf16_kernel<NT, NA2, TH>, seen);
     const size_t tiles = (size_t)p.N * p.tiles_y * p.tiles_x * p.co_blocks;
-    const size_t wgs = tiles < 256 ? tiles : 256;
+    // 32-channel tiles (conv0, the R|I layer): 18 - 36 MFMAs per wave and tile against a DMA round trip of several microseconds, with
+    // ONE tile of prefetch - a workgroup per CU waited ~15k cycles per tile for its operands.  Two workgroups fit a CU (2 x 77 KB of
+    // LDS, 116 registers) and cover each other's flight.
+    const size_t per_cu = (NT == 1 && ssie_bf16_two_wgs && 2 * (lds + 256) <= 160 * 1024 && tiles >= 512) ? 2 : 1;
+    const size_t wgs = tiles < 256 * per_cu ? tiles : 256 * per_cu;
     hipLaunchKernelGGL((conv_fprop_bf16_kernel<NT, NA2, TH>), dim3((unsigned)wgs), dim3(512), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : 61;
 }
