@@ -287,9 +287,10 @@ PackDesc ssie_make_pack_bf16(const float* w, float* dst, int K, int N, const Tap
 
 extern int ssie_wgrad_rows2, ssie_wgrad_sliding;
 int ssie_wgrad_wino = 1;              // A/B switch: 1 = stride-1 3x3 weight gradients on Winograd F(3x3,2x2) (conv_wgrad_wino.hip)
-int ssie_wgrad_wino_min_tiles = 256;  // ... when the launch has at least this many 8 x 16 position tiles (tests set 1)
+#define SSIE_WGRAD_WINO_MIN_TILES 64   // (256 until round 4: at the reference's shipped batch of 2 the 64 x 64 layers' 128 tiles are faster here too - train64 at batch 2 -0.8 %)
+int ssie_wgrad_wino_min_tiles = SSIE_WGRAD_WINO_MIN_TILES;  // ... when the launch has at least this many 8 x 16 position tiles (tests set 1)
 extern "C" void ssie_debug_set_wgrad_wino(int v) { ssie_wgrad_wino = v; }
-extern "C" void ssie_debug_set_wgrad_wino_min_tiles(int v) { ssie_wgrad_wino_min_tiles = v; }
+extern "C" void ssie_debug_set_wgrad_wino_min_tiles(int v) { ssie_wgrad_wino_min_tiles = v < 0 ? SSIE_WGRAD_WINO_MIN_TILES : v; }   // v < 0: the default
 int ssie_make_wgrad(WgradParams& p, const SrcDesc& src, int N, int Hv, int Wv, int ci0_weight,
                     const float* g, int g_cstride, int g_coff, int Cout, int Ho, int Wo, int si,
                     const TapList& t, float* slabs, int target_wgs)

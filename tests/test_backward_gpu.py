@@ -166,7 +166,7 @@ def forced_kernels(pkg, request):
     L.ssie_debug_set_tconv_min_tiles(32)
     L.ssie_debug_set_wino4_min_tiles(-1)              # the library's default
     L.ssie_debug_set_wino_min_tiles(-1)               # the library's default
-    L.ssie_debug_set_wgrad_wino_min_tiles(256)
+    L.ssie_debug_set_wgrad_wino_min_tiles(-1)
     L.ssie_debug_set_skinny_final(1)
     L.ssie_debug_set_spectral9(1)
     L.ssie_debug_set_fprop_min_tiles16(256)

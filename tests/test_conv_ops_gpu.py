@@ -43,7 +43,7 @@ def kernel_mode(H, request):
     L.ssie_debug_set_tconv_min_tiles(32)
     L.ssie_debug_set_wino4_min_tiles(-1)              # the library's default
     L.ssie_debug_set_wino_min_tiles(-1)               # the library's default
-    L.ssie_debug_set_wgrad_wino_min_tiles(256)
+    L.ssie_debug_set_wgrad_wino_min_tiles(-1)
     L.ssie_debug_set_fprop_min_tiles16(256)
     L.ssie_debug_set_fprop_wide_min_tiles(512)
     L.ssie_debug_set_fprop_v2_split_min_tiles(1024)
