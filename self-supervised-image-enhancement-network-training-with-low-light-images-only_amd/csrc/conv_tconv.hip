@@ -17,17 +17,20 @@ __device__ f32x4 tconv_zero_page[4];   // zero-initialised: source of padding sl
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
 namespace {
-constexpr int TC_TH = 16, TC_TW = 16, TC_HP = 17, TC_HP4 = TC_HP * TC_HP * 4;     // 1156 16-byte slots per halo tile
-constexpr int TC_NA = (TC_HP4 + 511) / 512;                                        // 3 DMA slots per lane
+constexpr int TC_TW = 16, TC_HP = 17;                                              // tile width / halo row pitch (pixels)
 constexpr int TC_BSZ = 9 * 4 * 64;                                                 // float4 per weight chunk (9 taps x 16 ci x 64 co)
 __device__ __forceinline__ constexpr int tc_class(int t) { return t == 0 ? 0 : t < 3 ? 1 : t < 5 ? 2 : 3; }
 }
 
-template <int EPI, bool RAG>       // epilogue shape (ssie_epi_shape) / some tile sticks out of the output: see conv_fprop_v2_kernel
+// TC_TH = 16 input rows per tile, or 8 (ssie_conv_to_tconv: launches whose 16-row tiles would leave more than half the CUs idle - the
+// reference's shipped batch of 2 patches: 32 tiles of 38 MFLOP each were 83 us per launch; 64 half tiles ~45)
+template <int EPI, bool RAG, int TC_TH = 16>       // epilogue shape (ssie_epi_shape) / some tile sticks out of the output: see conv_fprop_v2_kernel
 __global__ __launch_bounds__(512, 2) void conv_tconv_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    constexpr int NTHR = 512, NW = 8, BN = 64, MT = 2;
+    constexpr int TC_HP4 = (TC_TH + 1) * TC_HP * 4;                                // 1156 (612) 16-byte slots per halo tile
+    constexpr int TC_NA = (TC_HP4 + 511) / 512;                                    // 3 (2) DMA slots per lane
+    constexpr int NTHR = 512, NW = 8, BN = 64, MT = TC_TH / 8;
     f32x4* As0 = (f32x4*)smem_f;                    // [2][TC_HP4]
     f32x4* Bs0 = As0 + 2 * TC_HP4;                  // [2][TC_BSZ]
     int* s_next = (int*)(Bs0 + 2 * TC_BSZ);
@@ -164,7 +167,8 @@ __global__ __launch_bounds__(512, 2) void conv_tconv_kernel(const ConvParams p)
                         }                                                                                     \
                     }                                                                                         \
                 }
-                TC_EPI(0, 0) TC_EPI(0, 1) TC_EPI(1, 0) TC_EPI(1, 1) TC_EPI(2, 0) TC_EPI(2, 1) TC_EPI(3, 0) TC_EPI(3, 1)
+                TC_EPI(0, 0) TC_EPI(1, 0) TC_EPI(2, 0) TC_EPI(3, 0)
+                if constexpr (MT == 2) { TC_EPI(0, 1) TC_EPI(1, 1) TC_EPI(2, 1) TC_EPI(3, 1) }
 #undef TC_EPI
             }
         }
@@ -174,22 +178,25 @@ __global__ __launch_bounds__(512, 2) void conv_tconv_kernel(const ConvParams p)
 #undef TC_DECODE
 }
 
-size_t ssie_tconv_lds_bytes() { return (size_t)(2 * TC_HP4 + 2 * TC_BSZ) * 16 + 64; }
+size_t ssie_tconv_lds_bytes(int th) { return (size_t)(2 * (th + 1) * TC_HP * 4 + 2 * TC_BSZ) * 16 + 64; }
 
 // p from ssie_make_conv over the nine taps in class order (ssie_taps_transposed_all), si = 1, so = 2, single 1:1 source, 64 outputs
 int ssie_launch_tconv(const ConvParams& p, hipStream_t st)
 {
-    if (p.ntaps != 9 || p.si != 1 || p.so != 2 || p.nsrc != 1 || p.Cout_pad != 64 || p.th != TC_TH || p.tw != TC_TW ||
-        p.hp_h != TC_HP || p.hp_w != TC_HP || p.min_dy != 0 || p.min_dx != 0) return 51;
+    if (p.ntaps != 9 || p.si != 1 || p.so != 2 || p.nsrc != 1 || p.Cout_pad != 64 || (p.th != 16 && p.th != 8) || p.tw != TC_TW ||
+        p.hp_h != p.th + 1 || p.hp_w != TC_HP || p.min_dy != 0 || p.min_dx != 0) return 51;
     if (p.src[0].sy != 1.f || p.src[0].sx != 1.f || p.src[0].Hs != p.Hv || p.src[0].Ws != p.Wv) return 52;
+    if (p.tiles_y != ssie_ceil_div(p.Ho, p.th) || p.tiles_x != ssie_ceil_div(p.Wo, TC_TW)) return 51;
     const size_t tiles = (size_t)p.N * p.tiles_y * p.tiles_x;
     const dim3 grid((unsigned)(tiles < 256 ? tiles : 256));
-    const bool rag = p.Ho % TC_TH != 0 || p.Wo % TC_TW != 0 || p.Hout != 2 * p.Ho || p.Wout != 2 * p.Wo;
+    const bool rag = p.Ho % p.th != 0 || p.Wo % TC_TW != 0 || p.Hout != 2 * p.Ho || p.Wout != 2 * p.Wo;
     const int epi = ssie_epi_shape(p);
-    static unsigned seen[4] = {0, 0, 0, 0};
-#define TC_GO(E, R, SLOT) { ssie_allow_full_lds((const void*)conv_tconv_kernel<E, R>, seen[SLOT]); \
-                            hipLaunchKernelGGL((conv_tconv_kernel<E, R>), grid, dim3(512), ssie_tconv_lds_bytes(), st, p); }
-    if (rag) TC_GO(0, true, 0) else if (epi == 1) TC_GO(1, false, 1) else if (epi == 2) TC_GO(2, false, 2) else TC_GO(0, false, 3)
+    static unsigned seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define TC_GO(E, R, TH_, SLOT) { ssie_allow_full_lds((const void*)conv_tconv_kernel<E, R, TH_>, seen[SLOT]); \
+                                 hipLaunchKernelGGL((conv_tconv_kernel<E, R, TH_>), grid, dim3(512), ssie_tconv_lds_bytes(TH_), st, p); }
+#define TC_PICK(TH_, B) { if (rag) TC_GO(0, true, TH_, B) else if (epi == 1) TC_GO(1, false, TH_, B + 1) else if (epi == 2) TC_GO(2, false, TH_, B + 2) else TC_GO(0, false, TH_, B + 3) }
+    if (p.th == 16) TC_PICK(16, 0) else TC_PICK(8, 4)
+#undef TC_PICK
 #undef TC_GO
     return hipGetLastError() == hipSuccess ? 0 : 53;
 }

@@ -72,10 +72,14 @@ bool ssie_tconv_eligible(const SrcDesc& in, int N, int Hin, int Win, int Nc)
 }
 
 // re-target a geometry built over ssie_taps_transposed_all (si = 1, so = 2, Ho x Wo = the INPUT grid) at conv_tconv_kernel
+// (8-row tiles when the 16-row ones would leave more than half of the CUs without a tile)
+int ssie_tconv_half_tiles_below = 128;
+extern "C" void ssie_debug_set_tconv_half_tiles_below(int v) { ssie_tconv_half_tiles_below = v; }
 void ssie_conv_to_tconv(ConvParams& p)
 {
-    p.tconv = 1; p.th = 16; p.tw = 16; p.hp_h = 17; p.hp_w = 17;
-    p.tiles_y = ssie_ceil_div(p.Ho, 16); p.tiles_x = ssie_ceil_div(p.Wo, 16); p.co_blocks = 1;
+    const long tiles16 = (long)p.N * ssie_ceil_div(p.Ho, 16) * ssie_ceil_div(p.Wo, 16);
+    p.tconv = 1; p.th = tiles16 < ssie_tconv_half_tiles_below ? 8 : 16; p.tw = 16; p.hp_h = p.th + 1; p.hp_w = 17;
+    p.tiles_y = ssie_ceil_div(p.Ho, p.th); p.tiles_x = ssie_ceil_div(p.Wo, 16); p.co_blocks = 1;
 }
 
 // The kernels index activations with 32-bit element offsets (conv_wino.hip tb_, conv_wgrad_wino.hip tbx_/tbg_, conv_tconv.hip

@@ -152,6 +152,25 @@ def test_conv_transpose2d_fwd(H, cin, cout, h, w):
     close(from_dev(out, cout), ref)
 
 
+@pytest.mark.parametrize("cin,cout,h,w", [(128, 64, 16, 16), (64, 64, 9, 20), (64, 64, 24, 40)])
+def test_conv_transpose2d_16_row_tiles(H, kernel_mode, cin, cout, h, w):
+    """conv_tconv_kernel has two tile heights: 8 input rows where 16-row tiles would leave most CUs without one (every case of this
+    file, and the reference's shipped batch of 2), 16 rows otherwise (the bench sizes).  The cases above run the 8-row form in the
+    "tconv1" mode; this one forces 16 rows on the same shapes (incl. ragged 9 x 20 and a multi-tile 24 x 40)."""
+    if kernel_mode != "tconv1":
+        pytest.skip("the one-launch transposed convolution is forced in the tconv1 mode only")
+    L = H.lib()
+    L.ssie_debug_set_tconv_half_tiles_below(0)
+    try:
+        n = 2
+        x = rnd(n, cin, h, w, seed=1); wt = rnd(cin, cout, 3, 3, seed=2, scale=0.1); b = rnd(cout, seed=3)
+        ref = F.relu(F.conv_transpose2d(x, wt, b, stride=2, padding=1, output_padding=1))
+        out = H.conv_transpose2d_fwd(to_dev(H, x), wt.float().cuda(), b.float().cuda(), act=1)
+        close(from_dev(out, cout), ref)
+    finally:
+        L.ssie_debug_set_tconv_half_tiles_below(128)
+
+
 def _conv_grads(x, wt, stride, g, transposed=False):
     x = x.clone().requires_grad_(True); wt = wt.clone().requires_grad_(True)
     b = torch.zeros(wt.shape[1] if transposed else wt.shape[0], dtype=torch.float64, requires_grad=True)
