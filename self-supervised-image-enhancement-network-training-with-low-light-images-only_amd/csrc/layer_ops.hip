@@ -73,7 +73,7 @@ bool ssie_tconv_eligible(const SrcDesc& in, int N, int Hin, int Win, int Nc)
 
 // re-target a geometry built over ssie_taps_transposed_all (si = 1, so = 2, Ho x Wo = the INPUT grid) at conv_tconv_kernel
 // (8-row tiles when the 16-row ones would leave more than half of the CUs without a tile)
-int ssie_tconv_half_tiles_below = 128;
+int ssie_tconv_half_tiles_below = 257;   // (at most one 16-row tile per CU)
 extern "C" void ssie_debug_set_tconv_half_tiles_below(int v) { ssie_tconv_half_tiles_below = v; }
 void ssie_conv_to_tconv(ConvParams& p)
 {
