@@ -58,8 +58,11 @@ __device__ __forceinline__ const f32x4* ssie_virtual_addr(const SrcSel& s, bool 
 // TH = 16: stride-1 layers; TH = 8: stride-2 layers (8 x 16 output positions read a 17 x 33 halo)
 // EPI / RAG: epilogue shape (ssie_epi_shape) and "some tile sticks out of the output"; the plain / whole-tile instantiations carry a
 // fraction of the epilogue code (instantiated for the stride-2 geometry only, the one that runs at bench sizes)
-template <int NT, int NA2, int NW, int TH, int EPI = 0, bool RAG = true>
-__global__ __launch_bounds__(64 * NW, 2) void conv_fprop_v2_kernel(const ConvParams p)
+// TGM = taps a weight buffer holds: SSIE_TG, or 1 for the 1 x 1 layers' own instantiations - their LDS footprint is then 40 KB instead
+// of 106, and TWO workgroups fit a CU.  A 1 x 1 step is 16 MFMAs per wave against a DMA round trip of microseconds with one step of
+// prefetch: one workgroup per CU ran feature_fusion at 2 TB/s of a pure streaming pass.
+template <int NT, int NA2, int NW, int TH, int EPI = 0, bool RAG = true, int TGM = SSIE_TG>
+__global__ __launch_bounds__(64 * NW, (TGM == 1 ? 4 : 2)) void conv_fprop_v2_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     constexpr int BN = 32 * NT;
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_fprop_v2_kernel(const ConvPar
     constexpr int WM = (NT == 2) ? NW / 2 : NW;     // waves along M; a TH x 16 tile has TH/2 M-tiles of 2 x 16 positions
     constexpr int MT = (TH / 2) / WM;
     static_assert(MT >= 1, "tile too small for the wave grid");
-    constexpr int BSZ = SSIE_TG * 4 * BN;           // float4 per B buffer
+    constexpr int BSZ = TGM * 4 * BN;               // float4 per B buffer
     const int HP = p.hp_h * p.hp_w, HP4 = HP * 4;
     f32x4* As0 = (f32x4*)smem_f;                    // [2][HP4]
     f32x4* Bs0 = As0 + 2 * HP4;                     // [2][BSZ]
@@ -485,6 +488,9 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_v2w_kernel(const ConvParams
 INST_V2(1, 3, 8, 16) INST_V2(1, 5, 8, 16) INST_V2(2, 3, 8, 16) INST_V2(2, 5, 8, 16) INST_V2(1, 6, 4, 16) INST_V2(2, 5, 8, 8)
 #define INST_V2S(E) template __global__ void conv_fprop_v2_kernel<2, 5, 8, 8, E, false>(const ConvParams);
 INST_V2S(0) INST_V2S(1) INST_V2S(2)
+template __global__ void conv_fprop_v2_kernel<2, 3, 8, 16, 1, false, 1>(const ConvParams);       // 1 x 1, plain forward / plain data gradient, whole tiles
+template __global__ void conv_fprop_v2_kernel<2, 3, 8, 16, 2, false, 1>(const ConvParams);
+template __global__ void conv_fprop_v2_kernel<2, 3, 8, 16, 0, false, 1>(const ConvParams);       // (general epilogue: 128 registers + 4 spilled dwords under the four-waves-per-SIMD bound)
 #define INST_V2W(S) template __global__ void conv_fprop_v2w_kernel<5, S, 0, true>(const ConvParams); \
                     template __global__ void conv_fprop_v2w_kernel<5, S, 0, false>(const ConvParams); \
                     template __global__ void conv_fprop_v2w_kernel<5, S, 1, false>(const ConvParams); \
@@ -515,17 +521,20 @@ static int g_v2_split_min_tiles = 1024;   // ... for launches with at least this
 extern "C" void ssie_debug_set_fprop_v2_split(int on) { g_v2_split = on; }
 extern "C" void ssie_debug_set_fprop_v2_split_min_tiles(int v) { g_v2_split_min_tiles = v; }
 
-template <int NT, int NA2, int NW, int TH = 16, int EPI = 0, bool RAG = true>
+template <int NT, int NA2, int NW, int TH = 16, int EPI = 0, bool RAG = true, int TGM = SSIE_TG>
 static int launch_v2_t(const ConvParams& p, size_t lds, hipStream_t st)
 {
     static unsigned seen = 0;
-    ssie_allow_full_lds((const void*)conv_fprop_v2_kernel<NT, NA2, NW, TH, EPI, RAG>, seen);
+    ssie_allow_full_lds((const void*)conv_fprop_v2_kernel<NT, NA2, NW, TH, EPI, RAG, TGM>, seen);
     const size_t tiles = (size_t)p.N * p.tiles_y * p.tiles_x * p.co_blocks;
-    const size_t cap = NW == 8 ? 256 : 512;
+    const size_t cap = (NW == 8 && TGM == SSIE_TG) ? 256 : 512;          // (the 1-tap form: two 8-wave workgroups per CU)
     const size_t wgs = tiles < cap ? tiles : cap;
-    hipLaunchKernelGGL((conv_fprop_v2_kernel<NT, NA2, NW, TH, EPI, RAG>), dim3((unsigned)wgs), dim3(64 * NW), lds, st, p);
+    hipLaunchKernelGGL((conv_fprop_v2_kernel<NT, NA2, NW, TH, EPI, RAG, TGM>), dim3((unsigned)wgs), dim3(64 * NW), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : 18;
 }
+
+static int g_v2_onetap = 1;     // ssie_debug_set_fprop_v2_onetap: 0 = 1 x 1 layers on the general instantiation, one workgroup per CU
+extern "C" void ssie_debug_set_fprop_v2_onetap(int on) { g_v2_onetap = on; }
 
 // every tile of the launch lies inside the output (so the element-wise edge epilogue is never needed)
 static bool whole_tiles(const ConvParams& p, int th, int tw)
@@ -571,6 +580,14 @@ int ssie_launch_fprop_v2(const ConvParams& p, hipStream_t st)
         const int epi = ssie_epi_shape(p);
         return epi == 1 ? launch_v2_t<2, 5, 8, 8, 1, false>(p, lds, st) : epi == 2 ? launch_v2_t<2, 5, 8, 8, 2, false>(p, lds, st)
                                                                                   : launch_v2_t<2, 5, 8, 8, 0, false>(p, lds, st);
+    }
+    if (nt == 2 && na2 <= 3 && p.ntaps == 1 && g_v2_onetap && whole_tiles(p, 16, SSIE_TW) &&
+        (size_t)p.N * p.tiles_y * p.tiles_x * p.co_blocks >= (g_v2_onetap == 2 ? 1u : 512u)) {      // (2: tests - any size)
+        const int epi = ssie_epi_shape(p);
+        const size_t lds1 = 2 * ((size_t)p.hp_h * p.hp_w * 64 + (size_t)4 * 32 * nt * 16) + (size_t)SSIE_MAX_TAPS * 4 + 16;
+        if (epi == 1) return launch_v2_t<2, 3, 8, 16, 1, false, 1>(p, lds1, st);
+        if (epi == 2) return launch_v2_t<2, 3, 8, 16, 2, false, 1>(p, lds1, st);
+        return launch_v2_t<2, 3, 8, 16, 0, false, 1>(p, lds1, st);
     }
     if (nt == 2) return na2 <= 3 ? launch_v2_t<2, 3, 8>(p, lds, st) : launch_v2_t<2, 5, 8>(p, lds, st);
     return na2 <= 3 ? launch_v2_t<1, 3, 8>(p, lds, st) : launch_v2_t<1, 5, 8>(p, lds, st);

@@ -39,7 +39,9 @@ def kernel_mode(H, request):
         L.ssie_debug_set_fprop_min_tiles16(0)
         L.ssie_debug_set_fprop_wide_min_tiles(1 if request.param == "tile16x32" else 1 << 30)
         L.ssie_debug_set_fprop_v2_split_min_tiles(1 if request.param == "tile16x32" else 1 << 30)   # 32-channel layers: two 4-wave workgroups per CU
+    L.ssie_debug_set_fprop_v2_onetap(2 if request.param == "tile16x16" else 1)      # 1 x 1 layers: the 1-tap instantiation whatever the size
     yield request.param
+    L.ssie_debug_set_fprop_v2_onetap(1)
     L.ssie_debug_set_tconv_min_tiles(32)
     L.ssie_debug_set_wino4_min_tiles(-1)              # the library's default
     L.ssie_debug_set_wino_min_tiles(-1)               # the library's default
@@ -82,6 +84,7 @@ def close(got, ref, tol=TOL):
     (5, 32, 3, 1, 16, 16, 1),
     (5, 64, 9, 1, 24, 16, 0),
     (64, 192, 1, 1, 8, 32, 0),
+    (64, 64, 1, 1, 32, 16, 1),          # whole 16 x 16 tiles: the 1-tap two-workgroups-per-CU form in the tile16x16 mode
     (64, 64, 3, 1, 32, 64, 1),
     (96, 64, 3, 1, 20, 40, 0),
     (128, 128, 3, 1, 16, 48, 1),
@@ -191,6 +194,7 @@ def _conv_grads(x, wt, stride, g, transposed=False):
     (64, 32, 3, 1, 16, 16),
     (64, 1, 3, 1, 16, 16),
     (192, 64, 1, 1, 8, 16),
+    (64, 64, 1, 1, 16, 32),
     (5, 32, 3, 1, 16, 16),
     (128, 128, 3, 1, 16, 16),
     (31, 32, 3, 1, 18, 22),
