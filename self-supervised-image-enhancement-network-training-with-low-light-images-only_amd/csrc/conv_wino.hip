@@ -70,7 +70,7 @@ constexpr int W_HPB = (W_HP4 + 511) / 512 * 512;                                
 constexpr int W_PLANE = W_HPB / 4;          // slots per channel-quad plane (612 used)
 constexpr int W_HALF = W_HPH * (W_HPW / 2);   // slots per column-parity half plane (18 rows x 17 columns)
 static_assert(W_PLANE >= 2 * W_HALF, "halo plane too small");
-constexpr int W_BSZ = 16 * 4 * 32;                                                      // float4 per U chunk (16 xi x 16 ci x 32 co)
+constexpr int W_BSZ_MAX = 16 * 4 * 32;                                                  // float4 per U chunk (16 xi x 16 ci x 32 co), the 32-channel form
 
 }  // namespace
 
@@ -208,11 +208,16 @@ __device__ __forceinline__ void wino_epilogue16_ragged(const PT& p, const float 
 }
 }  // namespace
 
-template <bool SINGLE, bool UP, int EPI, bool RAG>
+// NH = 16-channel halves of output channels per workgroup: 2 (a 32-channel tile), or 1 for launches whose 32-channel tiles would leave
+// half the CUs without one (the reference's shipped batch of 2: 128 tiles per 64-channel layer) - twice the workgroups, each with half
+// the MFMAs and half of U; the input transform is repeated per workgroup, which an under-filled chip does not notice
+template <bool SINGLE, bool UP, int EPI, bool RAG, int NH = 2>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     constexpr int NTHR = 512;
+    constexpr int NC = 16 * NH;                     // output channels per workgroup
+    constexpr int W_BSZ = 16 * 4 * NC;              // float4 per U chunk (16 xi x 16 ci x NC co)
     f32x4* As0 = (f32x4*)smem_f;                    // [2][W_HPB]
     f32x4* Bs0 = As0 + 2 * W_HPB;                   // [2][W_BSZ]
     int* s_next = (int*)(Bs0 + 2 * W_BSZ);
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define WN_DECODE(T, N_, A0_, B0_, CO0_)                                                  \
     {                                                                                     \
         int q_ = (T);                                                                     \
-        CO0_ = (q_ % p.co_blocks) * 32; q_ /= p.co_blocks;                                \
+        CO0_ = (q_ % p.co_blocks) * NC; q_ /= p.co_blocks;                                \
         B0_ = (q_ % p.tiles_x) * W_TW; q_ /= p.tiles_x;                                   \
         A0_ = (q_ % p.tiles_y) * W_TH; N_ = q_ / p.tiles_y;                               \
     }
@@ -266,7 +271,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     }
     // U pieces: per-lane byte offset inside a piece pair (two (xi, q) rows of 32 float4), constant for the whole kernel
-    const unsigned u_lane = (unsigned)(((lane >> 5) * p.Cout_pad + (lane & 31)) * 16);
+    // (NH = 1: a piece = four (xi, q) rows of 16 float4)
+    const unsigned u_lane = NH == 2 ? (unsigned)(((lane >> 5) * p.Cout_pad + (lane & 31)) * 16) : (unsigned)(((lane >> 4) * p.Cout_pad + (lane & 15)) * 16);
+    constexpr int U_ROWS = NH == 2 ? 2 : 4, U_PIECES = 64 / U_ROWS / 8;      // rows per piece; pieces per wave and step
 #define WN_RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, (int)(bytes), 0x00020000)
 #define WN_BLDS(rs, lptr, vo, so) __builtin_amdgcn_raw_ptr_buffer_load_lds((rs), (__attribute__((address_space(3))) void*)(lptr), 16, (int)(vo), (int)(so), 0, 0)
 #define WN_PREFETCH(CHUNK, N_, A0_, B0_, CO0_, BUF, PART)                                                         \
@@ -275,15 +282,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if ((PART) == 2) {                                                                                    \
         } else if (UP) {                                                                                      \
             const f32x4* wsrc_ = (const f32x4*)p.wpacked + (size_t)(CHUNK) * 64 * p.Cout_pad + (CO0_);        \
-            _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                \
+            _Pragma("unroll") for (int q_ = 0; q_ < U_PIECES; ++q_) {                                         \
                 const int pc_ = q_ * 8 + wave;                    /* piece = two (xi, q) rows of 32 float4 */   \
-                GLDS16(wsrc_ + (unsigned)((pc_ * 2 + (lane >> 5)) * p.Cout_pad + (lane & 31)), bbuf_ + pc_ * 64); \
+                GLDS16((const char*)(wsrc_ + (unsigned)(pc_ * U_ROWS * p.Cout_pad)) + u_lane, bbuf_ + pc_ * 64);  \
             }                                                                                                 \
         } else {                                                                                              \
             const __amdgpu_buffer_rsrc_t ur_ = WN_RSRC((const f32x4*)p.wpacked + (size_t)(CHUNK) * 64 * p.Cout_pad + (CO0_), 0x7fffffff); \
-            _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                \
+            _Pragma("unroll") for (int q_ = 0; q_ < U_PIECES; ++q_) {                                         \
                 const int pc_ = q_ * 8 + wave;                                                                \
-                WN_BLDS(ur_, bbuf_ + pc_ * 64, u_lane, (unsigned)(pc_ * 2 * p.Cout_pad * 16));                \
+                WN_BLDS(ur_, bbuf_ + pc_ * 64, u_lane, (unsigned)(pc_ * U_ROWS * p.Cout_pad * 16));           \
             }                                                                                                 \
         }                                                                                                     \
         const SrcSel s_ = SINGLE ? ssie_only_src(p) : ssie_pick_src(p, (CHUNK) * SSIE_CK);                    \
@@ -340,16 +347,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     ST_DECL
 
     while (tile < total_tiles) {
-        f32x4 acc[16][2];
+        f32x4 acc[16][NH];
 #if !SSIE_WINO_ZEROC
 #pragma unroll
         for (int x = 0; x < 16; ++x)
 #pragma unroll
-            for (int c = 0; c < 2; ++c) acc[x][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < NH; ++c) acc[x][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #endif
-        float bv[2];
+        float bv[NH];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) bv[c] = (EPI != 2 && p.bias && co0 + 16 * c + tx < p.Cout) ? p.bias[co0 + 16 * c + tx] : 0.f;
+        for (int c = 0; c < NH; ++c) bv[c] = (EPI != 2 && p.bias && co0 + 16 * c + tx < p.Cout) ? p.bias[co0 + 16 * c + tx] : 0.f;
         int ntile = 0x7fffffff;
         int nn = n, na0 = a0, nb0 = b0, nco0 = co0;
 
@@ -374,7 +381,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (ntile < total_tiles) WN_DECODE(ntile, nn, na0, nb0, nco0)
             }
             const char* Ab = (const char*)(As0 + buf * W_HPB) + abase;
-            const f32x4* Bl = Bs0 + buf * W_BSZ + g * 32 + tx;
+            const f32x4* Bl = Bs0 + buf * W_BSZ + g * NC + tx;
             // the 4 x 4 patch of this lane's tile, channel quad g -> B^T d B, one transform row at a time; the additions are written
             // on float2 halves so that they compile to v_pk_add_f32 (half the VALU instructions)
             f32x2 d[4][4][2];
@@ -386,7 +393,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     d[a][b][0] = f32x2{t.x, t.y}; d[a][b][1] = f32x2{t.z, t.w};
                 }
             // U fragments are fetched one transform position ahead of the MFMAs that use them
-            f32x4 bfn0 = Bl[0], bfn1 = Bl[16];
+            f32x4 bfn0 = Bl[0], bfn1 = Bl[NH == 2 ? 16 : 0];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 f32x2 r[4][2], v[4][2];
@@ -406,11 +413,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int j = 0; j < 4; ++j) {
                     const int xi = i * 4 + j;
                     const f32x4 bf0 = bfn0, bf1 = bfn1;
-                    if (xi < 15) { bfn0 = Bl[((xi + 1) * 4) * 32]; bfn1 = Bl[((xi + 1) * 4) * 32 + 16]; }
+                    if (xi < 15) { bfn0 = Bl[((xi + 1) * 4) * NC]; if (NH == 2) bfn1 = Bl[((xi + 1) * 4) * NC + 16]; }
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         acc[xi][0] = MFMA16(v[j][c >> 1][c & 1], bf0[c], (FIRST && c == 0) ? zero4 : acc[xi][0]);
-                        acc[xi][1] = MFMA16(v[j][c >> 1][c & 1], bf1[c], (FIRST && c == 0) ? zero4 : acc[xi][1]);
+                        if (NH == 2) acc[xi][NH - 1] = MFMA16(v[j][c >> 1][c & 1], bf1[c], (FIRST && c == 0) ? zero4 : acc[xi][NH - 1]);
                     }
                 }
                 // the next step's DMA is issued AFTER the first transform row's MFMAs: right behind the barrier all 8 waves would
@@ -459,7 +466,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int oy0 = a0 + 2 * wave, ox0 = b0 + 8 * g;
             const bool full = !RAG || (a0 + W_TH <= p.Hout && b0 + W_TW <= p.Wout);      // RAG = false: the output is whole 16 x 32 tiles
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
+            for (int c = 0; c < NH; ++c) {
                 const int co = co0 + 16 * c + tx;
                 if (co >= p.Cout) continue;
                 float y[16];
@@ -500,15 +507,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         template __global__ void conv_wino_kernel<S, U, 2, false>(const ConvParams);
 WINO_INST(false, false) WINO_INST(true, false) WINO_INST(false, true) WINO_INST(true, true)
 #undef WINO_INST
+#define WINO_INST1(S, U) template __global__ void conv_wino_kernel<S, U, 0, false, 1>(const ConvParams); \
+                         template __global__ void conv_wino_kernel<S, U, 1, false, 1>(const ConvParams); \
+                         template __global__ void conv_wino_kernel<S, U, 2, false, 1>(const ConvParams);
+WINO_INST1(false, false) WINO_INST1(true, false) WINO_INST1(false, true) WINO_INST1(true, true)
+#undef WINO_INST1
 
 
-size_t ssie_wino_lds_bytes() { return (size_t)(2 * W_HPB + 2 * W_BSZ) * 16 + 64 + (size_t)W_HPB * 4; }
+size_t ssie_wino_lds_bytes() { return (size_t)(2 * W_HPB + 2 * W_BSZ_MAX) * 16 + 64 + (size_t)W_HPB * 4; }
+
+int ssie_wino_half_below = 256;        // 16-channel workgroups when the launch has fewer 32-channel tiles than this (one per CU)
+extern "C" void ssie_debug_set_wino_half_below(int v) { ssie_wino_half_below = v; }
 
 int ssie_launch_fprop_wino(const ConvParams& p, hipStream_t st)
 {
     if (p.ntaps != 9 || p.si != 1 || p.so != 1 || p.py || p.px || p.min_dy != -1 || p.min_dx != -1 || p.Cout_pad % 32) return 31;
     if (p.th != W_TH || p.tw != W_TW || p.hp_h != W_HPH || p.hp_w != W_HPW || p.co_blocks != p.Cout_pad / 32) return 32;
-    const size_t tiles = (size_t)p.N * p.tiles_y * p.tiles_x * p.co_blocks;
+    const size_t tiles32 = (size_t)p.N * p.tiles_y * p.tiles_x * p.co_blocks;
+    const bool rag = p.Hout % W_TH != 0 || p.Wout % W_TW != 0;       // some tile sticks out of the output: keep the element-wise epilogue
+    const bool half = !rag && (long)tiles32 < ssie_wino_half_below;   // under-filled: 16-channel workgroups (whole-tile launches only)
+    ConvParams ph = p;
+    if (half) ph.co_blocks = p.Cout_pad / 16;
+    const size_t tiles = half ? 2 * tiles32 : tiles32;
     const dim3 grid((unsigned)(tiles < 256 ? tiles : 256));
     const size_t lds = ssie_wino_lds_bytes();
     // the DMA table holds a slot's byte offset from the tile origin in 24 bits (18 halo rows); larger images take the arithmetic decode
@@ -520,9 +540,11 @@ int ssie_launch_fprop_wino(const ConvParams& p, hipStream_t st)
     const bool plain = !p.out2 && !p.addsrc;
     const int epi = (plain && !p.mask_y && !p.accumulate && p.act != ACT_SIGMOID) ? 1
                   : (plain && !p.bias && p.act == ACT_NONE && p.mask_mode != MASK_SIGMOID) ? 2 : 0;
-    const bool rag = p.Hout % W_TH != 0 || p.Wout % W_TW != 0;       // some tile sticks out of the output: keep the element-wise epilogue
     static unsigned seen[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define WINO_GO(S, U, E, SLOT) { if (rag) { ssie_allow_full_lds((const void*)conv_wino_kernel<S, U, E, true>, seen[SLOT]); \
+    static unsigned seen1[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define WINO_GO(S, U, E, SLOT) { if (half) { ssie_allow_full_lds((const void*)conv_wino_kernel<S, U, E, false, 1>, seen1[SLOT]); \
+                                             hipLaunchKernelGGL((conv_wino_kernel<S, U, E, false, 1>), grid, dim3(512), lds, st, ph); } \
+                                 else if (rag) { ssie_allow_full_lds((const void*)conv_wino_kernel<S, U, E, true>, seen[SLOT]); \
                                             hipLaunchKernelGGL((conv_wino_kernel<S, U, E, true>), grid, dim3(512), lds, st, p); } \
                                  else { ssie_allow_full_lds((const void*)conv_wino_kernel<S, U, E, false>, seen[12 + SLOT]); \
                                         hipLaunchKernelGGL((conv_wino_kernel<S, U, E, false>), grid, dim3(512), lds, st, p); } }

@@ -40,7 +40,10 @@ def kernel_mode(H, request):
         L.ssie_debug_set_fprop_wide_min_tiles(1 if request.param == "tile16x32" else 1 << 30)
         L.ssie_debug_set_fprop_v2_split_min_tiles(1 if request.param == "tile16x32" else 1 << 30)   # 32-channel layers: two 4-wave workgroups per CU
     L.ssie_debug_set_fprop_v2_onetap(2 if request.param == "tile16x16" else 1)      # 1 x 1 layers: the 1-tap instantiation whatever the size
+    # F(2x2,3x3) workgroup width: "winograd" = 16 output channels wherever the launch is whole tiles (the under-filled form), "winograd4" = 32
+    L.ssie_debug_set_wino_half_below(0 if request.param == "winograd4" else 1 << 30)
     yield request.param
+    L.ssie_debug_set_wino_half_below(256)
     L.ssie_debug_set_fprop_v2_onetap(1)
     L.ssie_debug_set_tconv_min_tiles(32)
     L.ssie_debug_set_wino4_min_tiles(-1)              # the library's default

@@ -71,6 +71,7 @@ def forced_kernels(pkg, request):
         L.ssie_debug_set_wino_min_tiles(1)
         L.ssie_debug_set_wgrad_wino_min_tiles(1)
         L.ssie_debug_set_tconv_min_tiles(1)       # and the one-launch transposed convolution (conv_tconv.hip)
+        L.ssie_debug_set_wino_half_below(0 if request.param == "winograd4" else 256)   # F(2x2) workgroups: 32 channels wide in the "winograd4" runs, 16 (under-filled launches) otherwise
     elif request.param:
         L.ssie_debug_set_wino4_min_tiles(1 << 30)
         L.ssie_debug_set_fprop_min_tiles16(0)
@@ -81,6 +82,7 @@ def forced_kernels(pkg, request):
         L.ssie_debug_set_skinny_final(0)          # and final_conv (64 -> 1) on the MFMA tiles instead of the VALU kernels
         L.ssie_debug_set_spectral9(0)             # and the 9 x 9 convolution on the direct MFMA kernels instead of the frequency domain
     yield request.param
+    L.ssie_debug_set_wino_half_below(256)
     L.ssie_debug_set_tconv_min_tiles(32)
     L.ssie_debug_set_wino4_min_tiles(-1)              # the library's default
     L.ssie_debug_set_wino_min_tiles(-1)               # the library's default
