@@ -63,7 +63,7 @@ void ssie_debug_set_loss_chunked(int v);                /* [0] 1 = the band-chun
 void ssie_debug_set_wino(int v);                        /* [1] 0 = stride-1 3x3 launches never run the Winograd F(2x2,3x3) kernel (plans created afterwards) */
 void ssie_debug_set_wino4(int v);                       /* [1] 0 = no stride-1 3x3 launch runs the Winograd F(4x4,3x3) kernel (conv_wino4.hip); plans created afterwards */
 void ssie_debug_set_wino4_min_tiles(int v);             /* [256] fewest 16x64x32-channel tiles for which it is chosen (tests: 1 = wherever eligible, 1 << 30 = never, < 0 = restore the default) */
-void ssie_debug_set_wino_min_tiles(int v);               /* [128] fewest 16x32x32-channel tiles for which it is chosen (< 0 = restore the default) */
+void ssie_debug_set_wino_min_tiles(int v);               /* [32] fewest 16x32x32-channel tiles for which it is chosen (< 0 = restore the default) */
 void ssie_debug_set_wgrad_wino(int v);                  /* [1] 0 = stride-1 3x3 weight gradients never run the Winograd F(3x3,2x2) kernel (plans created afterwards) */
 void ssie_debug_set_wgrad_wino_min_tiles(int v);        /* [64] fewest 8x16 position tiles for which it is chosen; v < 0 = the default */
 void ssie_debug_set_fused_tail(int on);                 /* [1] 0 = inference keeps feature_fusion / final_conv / compose as separate launches (plans bound afterwards) */

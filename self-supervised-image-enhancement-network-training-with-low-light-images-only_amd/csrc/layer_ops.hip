@@ -208,9 +208,9 @@ int ssie_make_conv_bf16(ConvParams& p, const SrcDesc* srcs, int nsrc, int N, int
 
 // ---- Winograd F(2x2, 3x3) (conv_wino.hip) ----
 int ssie_fprop_wino = 1;              // A/B switch: 1 = eligible stride-1 3x3 launches run conv_wino_kernel
-#define SSIE_WINO_MIN_TILES 128       // half a chip of tiles: at batch 2 of 128 x 128 (the reference's shipped configuration, 128 tiles per
-                                      // 64-channel layer) the Winograd kernel on half the CUs still beats the direct kernel on all of them
-                                      // (train64 at batch 2: 3.63 -> 3.40 ms per step; nothing changes at batch 32)
+#define SSIE_WINO_MIN_TILES 32        // 32-channel tiles.  128 (half a chip) until the kernel got its 16-channel-workgroup form for under-filled
+                                      // launches (conv_wino.hip NH = 1): with it, at batch 2 of 128 x 128 (the reference's shipped configuration) the
+                                      // 64- and 32-tile layers are faster on Winograd too (train64 at batch 2: 3.05 -> 2.95 ms; nothing changes at batch 32)
 int ssie_fprop_wino_min_tiles = SSIE_WINO_MIN_TILES;  // ... when the launch has at least this many 16 x 32 x 32-channel tiles (tests set 1)
 extern "C" void ssie_debug_set_wino(int v) { ssie_fprop_wino = v; }
 extern "C" void ssie_debug_set_wino_min_tiles(int v) { ssie_fprop_wino_min_tiles = v < 0 ? SSIE_WINO_MIN_TILES : v; }   // v < 0: the default
