@@ -56,7 +56,7 @@ void ssie_debug_set_fprop_v2_split(int on);             /* [1] 0 = one 8-wave wo
 void ssie_debug_set_fprop_v2_split_min_tiles(int v);    /* [1024] */
 void ssie_debug_set_fprop_wgs_per_cu(int v);
 void ssie_debug_set_tconv(int v);                       /* [1] 0 = stride-2 transposed 3x3 convolutions always as four output-parity launches (plans created afterwards) */
-void ssie_debug_set_tconv_min_tiles(int v);             /* [32] fewest 16x16 input tiles for the one-launch kernel */
+void ssie_debug_set_tconv_min_tiles(int v);             /* [8] fewest 16x16 input tiles for the one-launch kernel; v < 0 = the default */
 void ssie_debug_set_fft_grouped(int v);                 /* [1] 0 = Fourier loss planes that fit the LDS always run the whole-plane kernel (fft_loss_kernel); plans / operator calls made afterwards */
 void ssie_debug_set_loss_chunk_lpp(int v);              /* [8] lanes per pixel of loss_chunk_kernel: 8 = 32-band chunks on 8x16 tiles, 16 = 64-band chunks on 4x16 tiles */
 void ssie_debug_set_loss_chunked(int v);                /* [0] 1 = the band-chunked tiled loss kernel (loss_chunk_kernel, normally only above 252 bands) for every band count */

@@ -60,10 +60,11 @@ TapList ssie_taps_transposed_all(void)
 
 // ---- one-launch transposed convolution (conv_tconv.hip) ----
 int ssie_fprop_tconv = 1;              // A/B switch: 1 = eligible stride-2 transposed 3x3 convolutions run conv_tconv_kernel
-int ssie_fprop_tconv_min_tiles = 32;   // ... when the input has at least this many 16 x 16 tiles (tests set 1): below 256 tiles the four
+#define SSIE_TCONV_MIN_TILES 8          // (32 until the kernel got its 8-row tiles for under-filled launches: at batch 2 the 32 x 32 level is faster here too, -1 %)
+int ssie_fprop_tconv_min_tiles = SSIE_TCONV_MIN_TILES;   // ... when the input has at least this many 16 x 16 tiles (tests set 1): below 256 tiles the four
                                        // parity-class launches are launch-latency-bound (4 x ~20 us at the 16 x 16 / 32 x 32 pyramid levels)
 extern "C" void ssie_debug_set_tconv(int v) { ssie_fprop_tconv = v; }
-extern "C" void ssie_debug_set_tconv_min_tiles(int v) { ssie_fprop_tconv_min_tiles = v; }
+extern "C" void ssie_debug_set_tconv_min_tiles(int v) { ssie_fprop_tconv_min_tiles = v < 0 ? SSIE_TCONV_MIN_TILES : v; }   // v < 0: the default
 
 bool ssie_tconv_eligible(const SrcDesc& in, int N, int Hin, int Win, int Nc)
 {

@@ -163,7 +163,7 @@ def forced_kernels(pkg, request):
         L.ssie_debug_set_skinny_final(0)          # and final_conv (64 -> 1) on the MFMA tiles instead of the VALU kernels
         L.ssie_debug_set_spectral9(0)             # and the 9 x 9 convolution on the direct MFMA kernels instead of the frequency domain
     yield request.param
-    L.ssie_debug_set_tconv_min_tiles(32)
+    L.ssie_debug_set_tconv_min_tiles(-1)
     L.ssie_debug_set_wino4_min_tiles(-1)              # the library's default
     L.ssie_debug_set_wino_min_tiles(-1)               # the library's default
     L.ssie_debug_set_wgrad_wino_min_tiles(-1)

@@ -45,7 +45,7 @@ def kernel_mode(H, request):
     yield request.param
     L.ssie_debug_set_wino_half_below(256)
     L.ssie_debug_set_fprop_v2_onetap(1)
-    L.ssie_debug_set_tconv_min_tiles(32)
+    L.ssie_debug_set_tconv_min_tiles(-1)
     L.ssie_debug_set_wino4_min_tiles(-1)              # the library's default
     L.ssie_debug_set_wino_min_tiles(-1)               # the library's default
     L.ssie_debug_set_wgrad_wino_min_tiles(-1)
