@@ -70,6 +70,7 @@ void ssie_debug_set_fused_tail(int on);                 /* [1] 0 = inference kee
 void ssie_debug_set_spectral9(int on);                  /* [1] 0 = the 9 x 9 convolution (shallow_conv) on the direct MFMA kernels instead of the frequency domain (plans created afterwards) */
 void ssie_debug_set_fold_masks(int on);                 /* [1] 0 = the backward's ReLU / sigmoid masks as separate mask_axpy launches instead of second outputs of the producing launches (plans created afterwards) */
 void ssie_debug_set_batched_reduce(int on);             /* [1] 0 = one weight-gradient slab reduction per layer right behind its producer instead of ONE batched launch at the end of the backward pass (plans created afterwards; bit-identical either way) */
+void ssie_debug_set_tconv_split_below(int v);          /* [256] whole-tile 8-row launches of the one-launch transposed convolution with fewer tiles than this run 32-channel workgroups (0 = never) */
 void ssie_debug_set_wino_half_below(int v);            /* [256] whole-tile Winograd F(2x2,3x3) launches with fewer 32-channel tiles than this run 16-channel workgroups (0 = never) */
 void ssie_debug_set_fprop_v2_onetap(int on);            /* [1] 0 = 1 x 1 layers on the general 16 x 16-tile instantiation (one workgroup per CU) instead of the 1-tap one (40 KB of LDS, two per CU) */
 void ssie_debug_set_tconv_half_tiles_below(int v);     /* [257] the one-launch transposed convolution takes 8-row tiles when its 16-row tiles would number fewer than this (0 = always 16 rows) */

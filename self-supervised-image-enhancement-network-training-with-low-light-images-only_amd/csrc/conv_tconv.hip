@@ -18,19 +18,22 @@ __device__ f32x4 tconv_zero_page[4];   // zero-initialised: source of padding sl
 
 namespace {
 constexpr int TC_TW = 16, TC_HP = 17;                                              // tile width / halo row pitch (pixels)
-constexpr int TC_BSZ = 9 * 4 * 64;                                                 // float4 per weight chunk (9 taps x 16 ci x 64 co)
+constexpr int TC_BSZ_MAX = 9 * 4 * 64;                                             // float4 per weight chunk (9 taps x 16 ci x 64 co), the 64-channel form
 __device__ __forceinline__ constexpr int tc_class(int t) { return t == 0 ? 0 : t < 3 ? 1 : t < 5 ? 2 : 3; }
 }
 
 // TC_TH = 16 input rows per tile, or 8 (ssie_conv_to_tconv: launches whose 16-row tiles would leave more than half the CUs idle - the
 // reference's shipped batch of 2 patches: 32 tiles of 38 MFLOP each were 83 us per launch; 64 half tiles ~45)
-template <int EPI, bool RAG, int TC_TH = 16>       // epilogue shape (ssie_epi_shape) / some tile sticks out of the output: see conv_fprop_v2_kernel
-__global__ __launch_bounds__(512, 2) void conv_tconv_kernel(const ConvParams p)
+// NWN = waves along the output channels: 2 (a 64-channel tile, 8 waves), or 1 (32 channels, 4 waves) for launches that the 8-row tiles
+// still leave under-filled (batch 2: 64 tiles -> 128 workgroups, each staging the halo for half the channels)
+template <int EPI, bool RAG, int TC_TH = 16, int NWN = 2>       // epilogue shape (ssie_epi_shape) / some tile sticks out of the output: see conv_fprop_v2_kernel
+__global__ __launch_bounds__(256 * NWN, 2) void conv_tconv_kernel(const ConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    constexpr int NTHR = 256 * NWN, NW = 4 * NWN, BN = 32 * NWN, MT = TC_TH / 8;
     constexpr int TC_HP4 = (TC_TH + 1) * TC_HP * 4;                                // 1156 (612) 16-byte slots per halo tile
-    constexpr int TC_NA = (TC_HP4 + 511) / 512;                                    // 3 (2) DMA slots per lane
-    constexpr int NTHR = 512, NW = 8, BN = 64, MT = TC_TH / 8;
+    constexpr int TC_NA = (TC_HP4 + NTHR - 1) / NTHR;                              // DMA slots per lane
+    constexpr int TC_BSZ = 9 * 4 * BN;                                             // float4 per weight chunk (9 taps x 16 ci x BN co)
     f32x4* As0 = (f32x4*)smem_f;                    // [2][TC_HP4]
     f32x4* Bs0 = As0 + 2 * TC_HP4;                  // [2][TC_BSZ]
     int* s_next = (int*)(Bs0 + 2 * TC_BSZ);
@@ -38,7 +41,7 @@ __global__ __launch_bounds__(512, 2) void conv_tconv_kernel(const ConvParams p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, li = lane & 31;
-    const int wn = wave & 1, wm = wave >> 1;
+    const int wn = NWN == 2 ? (wave & 1) : 0, wm = NWN == 2 ? (wave >> 1) : wave;
 
     // byte offset of this lane's A fragment (k-quad 0; k-quad 1 = ^32) for (M-tile m, tap t): tile-invariant
     int aaddr[9][MT];
@@ -50,16 +53,18 @@ __global__ __launch_bounds__(512, 2) void conv_tconv_kernel(const ConvParams p)
             aaddr[t][m] = (hp * 4 + (h ^ ssie_swz(hp))) * 16;
         }
     const int nsteps = p.nchunks;
-    const int total_tiles = p.N * p.tiles_y * p.tiles_x;
-
-#define TC_DECODE(T, N_, A0_, B0_)                                                        \
+    const int total_tiles = p.N * p.tiles_y * p.tiles_x * (NWN == 2 ? 1 : 2);
+    // (NWN = 1: the two 32-channel halves of a position tile are neighbouring tile ids)
+#define TC_DECODE(T, N_, A0_, B0_, CO0_)                                                  \
     {                                                                                     \
         int q_ = (T);                                                                     \
+        CO0_ = 0;                                                                         \
+        if (NWN == 1) { CO0_ = (q_ & 1) * 32; q_ >>= 1; }                                 \
         B0_ = (q_ % p.tiles_x) * TC_TW; q_ /= p.tiles_x;                                  \
         A0_ = (q_ % p.tiles_y) * TC_TH; N_ = q_ / p.tiles_y;                              \
     }
     // DMA of chunk CHUNK of tile (N_, A0_, B0_): halo tile (slot id = i*NTHR + tid holds channel quad (id&3) ^ swz(pixel)) + weights
-#define TC_PREFETCH(CHUNK, N_, A0_, B0_, BUF)                                                                 \
+#define TC_PREFETCH(CHUNK, N_, A0_, B0_, CO0_, BUF)                                                               \
     {                                                                                                         \
         f32x4* abuf_ = As0 + (BUF) * TC_HP4;                                                                  \
         const unsigned long long zp_ = (unsigned long long)tconv_zero_page;                                   \
@@ -73,18 +78,19 @@ __global__ __launch_bounds__(512, 2) void conv_tconv_kernel(const ConvParams p)
             const unsigned long long a_ = (unsigned long long)(p.src[0].ptr + off_), m_ = ok_ ? ~0ull : 0ull;  \
             if (i_ + 1 < TC_NA || id_ < TC_HP4) GLDS16T((const f32x4*)((a_ & m_) | (zp_ & ~m_)), abuf_ + i_ * NTHR + wave * 64); \
         }                                                                                                     \
-        const f32x4* wsrc_ = (const f32x4*)p.wpacked + (size_t)(CHUNK) * 9 * 4 * p.Cout_pad;                  \
+        const f32x4* wsrc_ = (const f32x4*)p.wpacked + (size_t)(CHUNK) * 9 * 4 * p.Cout_pad + (CO0_);         \
         f32x4* bbuf_ = Bs0 + (BUF) * TC_BSZ;                                                                  \
-        for (int q_ = wave; q_ < 9 * 4; q_ += NW)                                                             \
-            GLDS16T(wsrc_ + (size_t)q_ * p.Cout_pad + lane, bbuf_ + q_ * 64);                                 \
+        /* a piece = 64 float4 = one (tap, k-quad) row of 64 channels, or two rows of 32 */                   \
+        for (int q_ = wave; q_ < 9 * 4 * BN / 64; q_ += NW)                                                   \
+            GLDS16T(wsrc_ + (size_t)(NWN == 2 ? q_ : 2 * q_ + (lane >> 5)) * p.Cout_pad + (NWN == 2 ? lane : (lane & 31)), bbuf_ + q_ * 64); \
     }
 
     int tile = blockIdx.x;
     if (tile >= total_tiles) return;
-    int n, a0, b0;
-    TC_DECODE(tile, n, a0, b0)
+    int n, a0, b0, co0;
+    TC_DECODE(tile, n, a0, b0, co0)
     int gstep = 0;
-    TC_PREFETCH(0, n, a0, b0, 0)
+    TC_PREFETCH(0, n, a0, b0, co0, 0)
     int fetched = 0x7fffffff;
 
     while (tile < total_tiles) {
@@ -95,9 +101,9 @@ __global__ __launch_bounds__(512, 2) void conv_tconv_kernel(const ConvParams p)
             for (int c = 0; c < 4; ++c)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][c][r] = 0.f;
-        const float bv = (p.bias && wn * 32 + li < p.Cout) ? p.bias[wn * 32 + li] : 0.f;
+        const float bv = (p.bias && co0 + wn * 32 + li < p.Cout) ? p.bias[co0 + wn * 32 + li] : 0.f;
         int ntile = 0x7fffffff;
-        int nn = n, na0 = a0, nb0 = b0;
+        int nn = n, na0 = a0, nb0 = b0, nco0 = co0;
 
         for (int step = 0; step < nsteps; ++step, ++gstep) {
             const int buf = gstep & 1;
@@ -110,10 +116,10 @@ __global__ __launch_bounds__(512, 2) void conv_tconv_kernel(const ConvParams p)
             __syncthreads();
             if (step == (nsteps > 1 ? 1 : 0)) {
                 ntile = *s_next;
-                if (ntile < total_tiles) TC_DECODE(ntile, nn, na0, nb0)
+                if (ntile < total_tiles) TC_DECODE(ntile, nn, na0, nb0, nco0)
             }
-            if (step + 1 < nsteps) TC_PREFETCH(step + 1, n, a0, b0, buf ^ 1)
-            else if (ntile < total_tiles) TC_PREFETCH(0, nn, na0, nb0, buf ^ 1)
+            if (step + 1 < nsteps) TC_PREFETCH(step + 1, n, a0, b0, co0, buf ^ 1)
+            else if (ntile < total_tiles) TC_PREFETCH(0, nn, na0, nb0, nco0, buf ^ 1)
 
             const char* Ab = (const char*)(As0 + buf * TC_HP4);
             const f32x4* Bl = Bs0 + buf * TC_BSZ + h * BN + wn * 32 + li;
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void conv_tconv_kernel(const ConvParams p)
         // epilogue: class c = (py, px) writes out[2a + py][2b + px]; wave (wm, wn) holds tile rows 4wm .. 4wm+3 (M-tile m = rows
         // 2(wm*MT+m), +1), channels 32wn .. 32wn+31
         {
-            const int co = wn * 32 + li;
+            const int co = co0 + wn * 32 + li;
             if (co < p.Cout) {
                 const long rowstride = 2L * p.Wout * p.out_cstride, pixstride = 2L * p.out_cstride;
                 // (written out per (class, M-tile): left as loops hipcc keeps them rolled - the fused epilogue is large - and indexes
@@ -172,13 +178,16 @@ __global__ __launch_bounds__(512, 2) void conv_tconv_kernel(const ConvParams p)
 #undef TC_EPI
             }
         }
-        n = nn; a0 = na0; b0 = nb0; tile = ntile;
+        n = nn; a0 = na0; b0 = nb0; co0 = nco0; tile = ntile;
     }
 #undef TC_PREFETCH
 #undef TC_DECODE
 }
 
-size_t ssie_tconv_lds_bytes(int th) { return (size_t)(2 * (th + 1) * TC_HP * 4 + 2 * TC_BSZ) * 16 + 64; }
+size_t ssie_tconv_lds_bytes(int th) { return (size_t)(2 * (th + 1) * TC_HP * 4 + 2 * TC_BSZ_MAX) * 16 + 64; }
+
+int ssie_tconv_split_below = 256;      // 8-row-tile launches with fewer tiles than this: 32-channel workgroups (NWN = 1)
+extern "C" void ssie_debug_set_tconv_split_below(int v) { ssie_tconv_split_below = v; }
 
 // p from ssie_make_conv over the nine taps in class order (ssie_taps_transposed_all), si = 1, so = 2, single 1:1 source, 64 outputs
 int ssie_launch_tconv(const ConvParams& p, hipStream_t st)
@@ -187,15 +196,23 @@ int ssie_launch_tconv(const ConvParams& p, hipStream_t st)
         p.hp_h != p.th + 1 || p.hp_w != TC_HP || p.min_dy != 0 || p.min_dx != 0) return 51;
     if (p.src[0].sy != 1.f || p.src[0].sx != 1.f || p.src[0].Hs != p.Hv || p.src[0].Ws != p.Wv) return 52;
     if (p.tiles_y != ssie_ceil_div(p.Ho, p.th) || p.tiles_x != ssie_ceil_div(p.Wo, TC_TW)) return 51;
-    const size_t tiles = (size_t)p.N * p.tiles_y * p.tiles_x;
-    const dim3 grid((unsigned)(tiles < 256 ? tiles : 256));
+    const size_t tiles1 = (size_t)p.N * p.tiles_y * p.tiles_x;
     const bool rag = p.Ho % p.th != 0 || p.Wo % TC_TW != 0 || p.Hout != 2 * p.Ho || p.Wout != 2 * p.Wo;
+    const bool split = p.th == 8 && !rag && (long)tiles1 < ssie_tconv_split_below;       // whole-tile launches only (fewer instantiations)
+    const size_t tiles = split ? 2 * tiles1 : tiles1;
+    const dim3 grid((unsigned)(tiles < 256 ? tiles : 256));
     const int epi = ssie_epi_shape(p);
     static unsigned seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define TC_GO(E, R, TH_, SLOT) { ssie_allow_full_lds((const void*)conv_tconv_kernel<E, R, TH_>, seen[SLOT]); \
                                  hipLaunchKernelGGL((conv_tconv_kernel<E, R, TH_>), grid, dim3(512), ssie_tconv_lds_bytes(TH_), st, p); }
 #define TC_PICK(TH_, B) { if (rag) TC_GO(0, true, TH_, B) else if (epi == 1) TC_GO(1, false, TH_, B + 1) else if (epi == 2) TC_GO(2, false, TH_, B + 2) else TC_GO(0, false, TH_, B + 3) }
-    if (p.th == 16) TC_PICK(16, 0) else TC_PICK(8, 4)
+    if (split) {
+        static unsigned seen1[3] = {0, 0, 0};
+#define TC_GO1(E, SLOT) { ssie_allow_full_lds((const void*)conv_tconv_kernel<E, false, 8, 1>, seen1[SLOT]); \
+                          hipLaunchKernelGGL((conv_tconv_kernel<E, false, 8, 1>), grid, dim3(256), ssie_tconv_lds_bytes(8), st, p); }
+        if (epi == 1) TC_GO1(1, 0) else if (epi == 2) TC_GO1(2, 1) else TC_GO1(0, 2)
+#undef TC_GO1
+    } else if (p.th == 16) TC_PICK(16, 0) else TC_PICK(8, 4)
 #undef TC_PICK
 #undef TC_GO
     return hipGetLastError() == hipSuccess ? 0 : 53;

@@ -38,7 +38,7 @@ _DEBUG_ENV = (("SSIE_OVERLAP", "ssie_debug_set_overlap"), ("SSIE_GRAPH", "ssie_d
               ("SSIE_REDUCE_WIDE_MIN", "ssie_debug_set_wgrad_reduce_wide_min"), ("SSIE_FFT_GROUPED", "ssie_debug_set_fft_grouped"),
               ("SSIE_LOSS_CHUNKED", "ssie_debug_set_loss_chunked"), ("SSIE_LOSS_CHUNK_LPP", "ssie_debug_set_loss_chunk_lpp"),
               ("SSIE_LOSS_GENERIC", "ssie_debug_set_loss_generic"), ("SSIE_V2_SPLIT", "ssie_debug_set_fprop_v2_split"),
-              ("SSIE_FOLD_MASKS", "ssie_debug_set_fold_masks"), ("SSIE_BATCHED_REDUCE", "ssie_debug_set_batched_reduce"), ("SSIE_BF16_TWO_WGS", "ssie_debug_set_bf16_two_wgs"), ("SSIE_WINO_HALF_BELOW", "ssie_debug_set_wino_half_below"), ("SSIE_V2_ONETAP", "ssie_debug_set_fprop_v2_onetap"), ("SSIE_TCONV_HALF_BELOW", "ssie_debug_set_tconv_half_tiles_below"), ("SSIE_QKV_FUSED", "ssie_debug_set_qkv_fused"),
+              ("SSIE_FOLD_MASKS", "ssie_debug_set_fold_masks"), ("SSIE_BATCHED_REDUCE", "ssie_debug_set_batched_reduce"), ("SSIE_BF16_TWO_WGS", "ssie_debug_set_bf16_two_wgs"), ("SSIE_TCONV_SPLIT_BELOW", "ssie_debug_set_tconv_split_below"), ("SSIE_WINO_HALF_BELOW", "ssie_debug_set_wino_half_below"), ("SSIE_V2_ONETAP", "ssie_debug_set_fprop_v2_onetap"), ("SSIE_TCONV_HALF_BELOW", "ssie_debug_set_tconv_half_tiles_below"), ("SSIE_QKV_FUSED", "ssie_debug_set_qkv_fused"),
               ("SSIE_WINO4_MIN_TILES", "ssie_debug_set_wino4_min_tiles"), ("SSIE_WINO_MIN_TILES", "ssie_debug_set_wino_min_tiles"),
               ("SSIE_WGRAD_WINO_MIN_TILES", "ssie_debug_set_wgrad_wino_min_tiles"), ("SSIE_TCONV_MIN_TILES", "ssie_debug_set_tconv_min_tiles"))
 
