@@ -229,11 +229,12 @@ def run_train(args, torch, dist, hostlib, model, world, rank, dev):
 
     if rank == 0 and not args.no_roofline:
         plan = net._plan_for(x)
-        agg = None
+        # per-class device time = the MEDIAN of three event-bracketed passes (a one-off stall in one pass - a lazily loaded code object,
+        # a page-in - once put 23 ms on the 0.03 ms weight-packing launch and made it the "dominant" class); scaled by reps so that the
+        # per-step divisions below stay as they were
         reps = 3
-        for _ in range(reps):
-            pr = plan.profile_step(x)
-            agg = pr if agg is None else {k: (agg[k][0] + v[0], agg[k][1] + v[1], agg[k][2] + v[2]) for k, v in pr.items()}
+        runs = [plan.profile_step(x) for _ in range(reps)]
+        agg = {k: (sorted(r[k][0] for r in runs)[reps // 2] * reps, runs[0][k][1] * reps, runs[0][k][2] * reps) for k in runs[0]}
         dom = max(agg, key=lambda k: agg[k][0])
         ms, fl, cnt = agg[dom]
         # a Winograd F(2x2,3x3) launch executes 16/36 of the direct convolution's multiplications: the MFMA roofline is priced on
@@ -352,15 +353,19 @@ def run_infer(args, torch, hostlib, model, dev):
         ms = (C.c_double * cap)(); fl = (C.c_double * cap)(); kinds = (C.c_int * cap)(); tags = C.create_string_buffer(1 << 16)
         L.ssie_plan_profile_list.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_long), C.c_void_p, C.c_int, C.POINTER(C.c_double),
                                              C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int, C.c_char_p, C.c_int]
-        agg = {}
         reps = 3
+        runs = []
         for _ in range(reps):
             n = L.ssie_plan_profile_list(plan.h, x.data_ptr(), plan._strides(x), torch.cuda.current_stream().cuda_stream, int(bf16),
                                          ms, fl, kinds, cap, tags, 1 << 16)
             assert n > 0, n
+            one = {}
             for i in range(n):
                 k = hostlib.Plan.KINDS[kinds[i]]
-                a = agg.setdefault(k, [0.0, 0.0, 0]); a[0] += ms[i]; a[1] += fl[i]; a[2] += 1
+                a = one.setdefault(k, [0.0, 0.0, 0]); a[0] += ms[i]; a[1] += fl[i]; a[2] += 1
+            runs.append(one)
+        # median over the passes per class, scaled by reps (see run_train)
+        agg = {k: [sorted(r[k][0] for r in runs)[reps // 2] * reps, runs[0][k][1] * reps, runs[0][k][2] * reps] for k in runs[0]}
         dom = max(agg, key=lambda k: agg[k][0])
         dms, dfl, dcnt = agg[dom]
         executed = executed_fraction(dom)   # the MFMA roofline is priced on EXECUTED FLOPs (see run_train)
